@@ -1,0 +1,297 @@
+"""ctypes binding of the C ABI declared in include/azgym.h.
+
+``Engine`` wraps one ``azg_engine*``.  The symbol prefix is a parameter only so that the test-suite can
+bind the CPU oracle (prefix ``azo_``) through the same code; the product always binds ``azg_`` from
+``csrc/libazgym_hip.so`` (see ``_native.py``).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+ABI_VERSION = 1
+
+AZG_OK = 0
+AZG_E_INVALID = -1
+AZG_E_TERMINAL_ROOT = -2
+AZG_E_DEVICE = -3
+AZG_E_STATE = -4
+AZG_E_UNSUPPORTED = -5
+
+ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1 = 0, 1, 2
+MODE_DISCRETE, MODE_CONTINUOUS = 0, 1
+VT = {"off_policy": 0, "on_policy": 1, "greedy": 2}
+ACT = {"relu": 0, "elu": 1}
+MAX_HIDDEN = 8
+
+PENDULUM_R_SCALE = 16.2736044  # alphazero/search/mcts.py:20
+
+
+class AzgConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("device_id", C.c_int32),
+        ("env_id", C.c_int32),
+        ("mode", C.c_int32),
+        ("n_trees", C.c_int32),
+        ("n_sims", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("v_target", C.c_int32),
+        ("tree_id_base", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("c_uct", C.c_double),
+        ("gamma", C.c_double),
+        ("epsilon", C.c_double),
+        ("c_pw", C.c_double),
+        ("kappa", C.c_double),
+        ("reward_scale", C.c_double),
+        ("action_bound", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
+class AzgMlpDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("in_dim", C.c_int32),
+        ("n_hidden", C.c_int32),
+        ("hidden", C.c_int32 * MAX_HIDDEN),
+        ("n_dist", C.c_int32),
+        ("activation", C.c_int32),
+        ("log_std_min", C.c_float),
+        ("log_std_max", C.c_float),
+    ]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"azgym error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+SYMBOLS = [
+    "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_search_index", "search",
+    "results", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
+    "synthetic_roots", "last_search_ms", "upload_roots", "search_resident", "sync",
+]
+
+
+def bind(lib, prefix):
+    """Resolve every entry point of include/azgym.h on ``lib`` and set its prototype."""
+    f = {}
+    for s in SYMBOLS:
+        f[s] = getattr(lib, prefix + s)
+    vp = C.c_void_p
+    f["abi_version"].restype = C.c_int
+    f["engine_create"].argtypes = [C.POINTER(AzgConfig), C.POINTER(vp)]
+    f["engine_destroy"].argtypes = [vp]
+    f["engine_destroy"].restype = None
+    f["last_error"].argtypes = [vp]
+    f["last_error"].restype = C.c_char_p
+    f["set_weights"].argtypes = [vp, C.POINTER(AzgMlpDesc), C.POINTER(C.c_float), C.c_size_t]
+    f["set_search_index"].argtypes = [vp, C.c_uint32]
+    f["search"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    f["results"].argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    f["root_children"].argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    f["root_eval"].argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    f["dump_tree"].argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                               C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+    for s in ("max_children", "max_records", "env_state_dim", "obs_dim"):
+        f[s].argtypes = [vp]
+    f["synthetic_roots"].argtypes = [vp, C.POINTER(C.c_double)]
+    f["last_search_ms"].argtypes = [vp, C.POINTER(C.c_float)]
+    f["upload_roots"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    f["search_resident"].argtypes = [vp]
+    f["sync"].argtypes = [vp]
+    return f
+
+
+def policy_blob(policy):
+    """Flatten a torch policy (network/policies.py) into (AzgMlpDesc, float32 blob) in state_dict order."""
+    hidden = list(policy.hidden_dimensions)
+    desc = AzgMlpDesc()
+    desc.struct_size = C.sizeof(AzgMlpDesc)
+    desc.in_dim = policy.state_dim
+    desc.n_hidden = len(hidden)
+    for i, h in enumerate(hidden):
+        desc.hidden[i] = h
+    desc.n_dist = policy.dist_head.out_features
+    desc.activation = ACT[policy.nonlinearity]
+    desc.log_std_min = float(getattr(policy, "log_param_min", -5.0))
+    desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
+    parts = []
+    for mod in policy.trunk:
+        if hasattr(mod, "weight") and mod.weight.dim() == 2:
+            parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
+    parts += [policy.value_head.weight.detach().cpu().numpy().ravel(), policy.value_head.bias.detach().cpu().numpy().ravel()]
+    parts += [policy.dist_head.weight.detach().cpu().numpy().ravel(), policy.dist_head.bias.detach().cpu().numpy().ravel()]
+    blob = np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+    return desc, blob
+
+
+def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=2.0):
+    desc = AzgMlpDesc()
+    desc.struct_size = C.sizeof(AzgMlpDesc)
+    desc.in_dim = in_dim
+    desc.n_hidden = len(hidden)
+    for i, h in enumerate(hidden):
+        desc.hidden[i] = h
+    desc.n_dist = n_dist
+    desc.activation = ACT[activation] if isinstance(activation, str) else activation
+    desc.log_std_min = log_std_min
+    desc.log_std_max = log_std_max
+    return desc
+
+
+class Engine:
+    """One batched MCTS engine (B trees).  Mirrors MCTS*.__init__ kwargs (alphazero/search/mcts.py:316-327, 537-549)."""
+
+    def __init__(self, fns, *, env_id, mode, n_trees, n_sims, c_uct, gamma, epsilon=0.0, num_actions=0, c_pw=1.0,
+                 kappa=0.5, v_target="off_policy", reward_scale=PENDULUM_R_SCALE, action_bound=2.0, seed=34,
+                 tree_id_base=0, device_id=0):
+        self._f = fns
+        self._h = C.c_void_p()
+        cfg = AzgConfig()
+        cfg.struct_size = C.sizeof(AzgConfig)
+        cfg.device_id = device_id
+        cfg.env_id = env_id
+        cfg.mode = mode
+        cfg.n_trees = n_trees
+        cfg.n_sims = n_sims
+        cfg.num_actions = num_actions
+        cfg.v_target = VT[v_target] if isinstance(v_target, str) else v_target
+        cfg.tree_id_base = tree_id_base
+        cfg.c_uct = float(c_uct)
+        cfg.gamma = float(gamma)
+        cfg.epsilon = float(epsilon)
+        cfg.c_pw = float(c_pw)
+        cfg.kappa = float(kappa)
+        cfg.reward_scale = float(reward_scale)
+        cfg.action_bound = float(action_bound)
+        cfg.seed = int(seed)
+        self.cfg = cfg
+        rc = fns["engine_create"](C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise EngineError(rc, (fns["last_error"](None) or b"").decode())
+        self.n_trees = n_trees
+        self.n_sims = n_sims
+        self.mode = mode
+        self.kmax = fns["max_children"](self._h)
+        self.max_records = fns["max_records"](self._h)
+        self.s_env = fns["env_state_dim"](self._h)
+        self.s_obs = fns["obs_dim"](self._h)
+        self.n_dist = num_actions if mode == MODE_DISCRETE else 2
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = (self._f["last_error"](self._h) or b"").decode()
+            if rc == AZG_E_TERMINAL_ROOT:
+                raise ValueError(msg or "Can't do tree search from a terminal node")
+            raise EngineError(rc, msg)
+
+    def close(self):
+        if self._h:
+            self._f["engine_destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, desc, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(self._f["set_weights"](self._h, C.byref(desc), _ptr(blob, C.c_float), blob.size))
+
+    def set_policy(self, policy):
+        desc, blob = policy_blob(policy)
+        self.set_weights(desc, blob)
+
+    def set_search_index(self, idx):
+        self._check(self._f["set_search_index"](self._h, int(idx)))
+
+    def _roots(self, roots, carry):
+        roots = np.ascontiguousarray(roots, dtype=np.float64).reshape(self.n_trees, self.s_env)
+        if carry is not None:
+            carry = np.ascontiguousarray(carry, dtype=np.int32).reshape(self.n_trees)
+        return roots, carry
+
+    def search(self, roots, carry=None):
+        roots, carry = self._roots(roots, carry)
+        self._check(self._f["search"](self._h, _ptr(roots, C.c_double), _ptr(carry, C.c_int32)))
+
+    def upload_roots(self, roots, carry=None):
+        roots, carry = self._roots(roots, carry)
+        self._check(self._f["upload_roots"](self._h, _ptr(roots, C.c_double), _ptr(carry, C.c_int32)))
+
+    def search_resident(self):
+        self._check(self._f["search_resident"](self._h))
+
+    def sync(self):
+        self._check(self._f["sync"](self._h))
+
+    def last_search_ms(self):
+        ms = C.c_float()
+        self._check(self._f["last_search_ms"](self._h, C.byref(ms)))
+        return ms.value
+
+    def synthetic_roots(self):
+        roots = np.empty((self.n_trees, self.s_env), dtype=np.float64)
+        self._check(self._f["synthetic_roots"](self._h, _ptr(roots, C.c_double)))
+        return roots
+
+    def results(self):
+        B, K = self.n_trees, self.kmax
+        actions = np.empty((B, K), np.float32)
+        counts = np.empty((B, K), np.int32)
+        Q = np.empty((B, K), np.float64)
+        vt = np.empty((B,), np.float64)
+        nc = np.empty((B,), np.int32)
+        self._check(self._f["results"](self._h, _ptr(actions, C.c_float), _ptr(counts, C.c_int32), _ptr(Q, C.c_double),
+                                       _ptr(vt, C.c_double), _ptr(nc, C.c_int32)))
+        return {"actions": actions, "counts": counts, "Q": Q, "v_target": vt, "n_children": nc}
+
+    def root_children(self):
+        B, K = self.n_trees, self.kmax
+        child_n = np.empty((B, K), np.int32)
+        child_state = np.empty((B, K, self.s_env), np.float64)
+        self._check(self._f["root_children"](self._h, _ptr(child_n, C.c_int32), _ptr(child_state, C.c_double)))
+        return child_n, child_state
+
+    def root_eval(self):
+        value = np.empty((self.n_trees,), np.float32)
+        dist = np.empty((self.n_trees, self.n_dist), np.float32)
+        self._check(self._f["root_eval"](self._h, _ptr(value, C.c_float), _ptr(dist, C.c_float)))
+        return value, dist
+
+    def dump_tree(self):
+        B, R = self.n_trees, self.max_records
+        d = {
+            "n_records": np.empty((B,), np.int32),
+            "parent": np.empty((B, R), np.int32),
+            "edge_n": np.empty((B, R), np.int32),
+            "edge_W": np.empty((B, R), np.float64),
+            "edge_Q": np.empty((B, R), np.float64),
+            "edge_action": np.empty((B, R), np.float32),
+            "node_n": np.empty((B, R), np.int32),
+            "node_r": np.empty((B, R), np.float64),
+            "node_V": np.empty((B, R), np.float32),
+            "node_flags": np.empty((B, R), np.uint8),
+        }
+        self._check(self._f["dump_tree"](
+            self._h, _ptr(d["n_records"], C.c_int32), _ptr(d["parent"], C.c_int32), _ptr(d["edge_n"], C.c_int32),
+            _ptr(d["edge_W"], C.c_double), _ptr(d["edge_Q"], C.c_double), _ptr(d["edge_action"], C.c_float),
+            _ptr(d["node_n"], C.c_int32), _ptr(d["node_r"], C.c_double), _ptr(d["node_V"], C.c_float),
+            _ptr(d["node_flags"], C.c_uint8)))
+        return d
+
+
+def pw_table(c_pw, kappa, n):
+    """NodeContinuous.check_pw's threshold (alphazero/search/states.py:271-273) for visit counts 0..n-1."""
+    return [math.ceil(c_pw * ((i + 1) ** kappa)) for i in range(n)]

@@ -1,0 +1,159 @@
+"""Closed-form classic-control environments (numpy float64 restatement).
+
+The reference gets its environments from the third-party ``gym`` package (``rl/make_game.py:49-68``,
+``gym==0.19.0`` in requirements.txt:10), which is neither vendored in the reference nor installed here.
+These classes restate the published CartPole / Pendulum dynamics with the gym 0.19 ``Env`` call
+surface the reference's MCTS uses: ``copy.deepcopy(Env)`` + ``Env.step(action)`` returning
+``(obs, reward, done, info)`` (alphazero/search/mcts.py:443-449, 680-687), ``Env.reset()``, ``Env.seed()``.
+
+They are the definition of "the environment" for every parity claim in this repo (env
+parity is *unpinned* against gym itself).  One deliberate choice: a float32 action is widened to
+float64 before it enters the arithmetic, so the step is pure float64 under every NumPy version.
+The device kernels and the C oracle implement the same operation order.
+"""
+import math
+
+import numpy as np
+
+ENV_CARTPOLE = 0
+ENV_PENDULUM_V0 = 1
+ENV_PENDULUM_V1 = 2
+
+
+class _Box:
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.full(shape, low, dtype=dtype) if np.isscalar(low) else np.asarray(low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype) if np.isscalar(high) else np.asarray(high, dtype=dtype)
+        self.shape = tuple(shape)
+        self.dtype = dtype
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n = n
+        self.shape = ()
+        self.dtype = np.int64
+
+
+class _EnvBase:
+    azg_env_id = -1
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def close(self):
+        pass
+
+    def azg_state(self):
+        """float64 internal state vector handed to the engine as the search root."""
+        return np.asarray(self.state, dtype=np.float64)
+
+
+class CartPoleEnv(_EnvBase):
+    """gym ``CartPole-v0/v1`` dynamics (explicit Euler); TimeLimit is stripped by make_game (rl/make_game.py:61-62)."""
+
+    azg_env_id = ENV_CARTPOLE
+    gravity = 9.8
+    masscart = 1.0
+    masspole = 0.1
+    total_mass = masspole + masscart
+    length = 0.5
+    polemass_length = masspole * length
+    force_mag = 10.0
+    tau = 0.02
+    theta_threshold_radians = 12 * 2 * math.pi / 360
+    x_threshold = 2.4
+
+    def __init__(self, state=None):
+        high = np.array([self.x_threshold * 2, np.finfo(np.float32).max, self.theta_threshold_radians * 2, np.finfo(np.float32).max])
+        self.observation_space = _Box(-high, high, (4,))
+        self.action_space = _Discrete(2)
+        self.seed(None)
+        self.state = None if state is None else tuple(float(v) for v in state)
+
+    def reset(self):
+        self.state = tuple(float(v) for v in self.np_random.uniform(low=-0.05, high=0.05, size=(4,)))
+        return np.array(self.state, dtype=np.float32)
+
+    def step(self, action):
+        x, x_dot, theta, theta_dot = self.state
+        force = self.force_mag if int(action) == 1 else -self.force_mag
+        costheta = math.cos(theta)
+        sintheta = math.sin(theta)
+        temp = (force + (self.polemass_length * (theta_dot * theta_dot)) * sintheta) / self.total_mass
+        thetaacc = (self.gravity * sintheta - costheta * temp) / (
+            self.length * (4.0 / 3.0 - (self.masspole * (costheta * costheta)) / self.total_mass)
+        )
+        xacc = temp - ((self.polemass_length * thetaacc) * costheta) / self.total_mass
+        x = x + self.tau * x_dot
+        x_dot = x_dot + self.tau * xacc
+        theta = theta + self.tau * theta_dot
+        theta_dot = theta_dot + self.tau * thetaacc
+        self.state = (x, x_dot, theta, theta_dot)
+        done = bool(
+            x < -self.x_threshold or x > self.x_threshold or theta < -self.theta_threshold_radians or theta > self.theta_threshold_radians
+        )
+        return np.array(self.state, dtype=np.float32), 1.0, done, {}
+
+
+class PendulumEnv(_EnvBase):
+    """gym ``Pendulum-v0`` (``version=0``: speed clipped after integrating theta) / ``Pendulum-v1`` (clipped before)."""
+
+    max_speed = 8.0
+    max_torque = 2.0
+    dt = 0.05
+    g = 10.0
+    m = 1.0
+    l = 1.0
+
+    def __init__(self, state=None, version=1):
+        assert version in (0, 1)
+        self.version = version
+        self.azg_env_id = ENV_PENDULUM_V1 if version == 1 else ENV_PENDULUM_V0
+        high = np.array([1.0, 1.0, self.max_speed], dtype=np.float32)
+        self.observation_space = _Box(-high, high, (3,))
+        self.action_space = _Box(-self.max_torque, self.max_torque, (1,))
+        self.seed(None)
+        self.state = None if state is None else np.asarray(state, dtype=np.float64)
+
+    def reset(self):
+        high = np.array([np.pi, 1.0])
+        self.state = self.np_random.uniform(low=-high, high=high)
+        return self._get_obs()
+
+    def _get_obs(self):
+        th, thdot = self.state
+        return np.array([np.cos(th), np.sin(th), thdot])
+
+    def step(self, u):
+        th, thdot = (float(v) for v in self.state)
+        uc = np.clip(np.asarray(u, dtype=np.float32).reshape(-1)[0], np.float32(-self.max_torque), np.float32(self.max_torque))
+        u = float(uc)
+        an = ((th + math.pi) % (2.0 * math.pi)) - math.pi
+        costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u)
+        if self.version == 1:
+            newthdot = thdot + (15.0 * math.sin(th) + 3.0 * u) * self.dt
+            newthdot = min(max(newthdot, -self.max_speed), self.max_speed)
+            newth = th + newthdot * self.dt
+        else:
+            newthdot = thdot + (-15.0 * math.sin(th + math.pi) + 3.0 * u) * self.dt
+            newth = th + newthdot * self.dt
+            newthdot = min(max(newthdot, -self.max_speed), self.max_speed)
+        self.state = np.array([newth, newthdot])
+        # shape-(1,) reward like gym's when the action is a length-1 array (keeps the reference's Q shape (K,1))
+        return self._get_obs(), np.array([-costs]), False, {}
+
+
+def make_game(game: str):
+    """Counterpart of rl/make_game.py:49-68 for the closed-form envs (no wrappers, no TimeLimit)."""
+    name = game.split("-")[0].lower()
+    if name == "cartpole":
+        return CartPoleEnv()
+    if name == "pendulum":
+        return PendulumEnv(version=0 if game.endswith("v0") else 1)
+    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole and Pendulum only")

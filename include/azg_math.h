@@ -1,0 +1,232 @@
+/*
+ * azg_math.h -- bit-reproducible elementary functions + Philox for the azgym MCTS engine.
+ *
+ * Every function here is built ONLY from IEEE-754 correctly rounded primitives
+ * (+, -, *, /, sqrt, fma) and integer/bit operations, written out in one fixed
+ * evaluation order.  Compiled with -ffp-contract=off on both sides, the host
+ * (gcc) and the gfx950 device (hipcc) therefore produce bit-identical results,
+ * which is what lets tests/ compare the HIP search against the CPU oracle
+ * bit-for-bit (visit counts, Q, W, actions) instead of within a tolerance.
+ *
+ * What each function stands in for in the reference (file:line under /root/reference):
+ *   azg_expf / azg_expm1f / azg_tanhf  torch ELU, exp(log_std), softmax, tanh squash
+ *                                      (alphazero/network/policies.py:101-120, 456-462;
+ *                                       alphazero/network/distributions.py:63)
+ *   azg_sincos, azg_pymod              numpy float64 sin/cos/% inside gym's classic-control
+ *                                      dynamics (call sites alphazero/search/mcts.py:449, 686)
+ *   azg_philox4x32, azg_normal         the engine's own counter-based RNG (the reference draws from
+ *                                      torch/python global generators: policies.py:497, helpers.py:51)
+ * Accuracy is <= 2 ulp against libm for the ranges used (checked in tests/test_math.py);
+ * agreement with torch/numpy is therefore far inside the 1e-5 parity tolerance.
+ */
+#ifndef AZG_MATH_H
+#define AZG_MATH_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define AZG_HD __host__ __device__ __forceinline__
+#else
+#define AZG_HD static inline
+#endif
+
+#define AZG_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
+#define AZG_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+AZG_HD uint32_t azg_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+AZG_HD float azg_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+AZG_HD uint64_t azg_d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+AZG_HD double azg_u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
+
+/* ---------------------------------------------------------------- float32 */
+
+/* e^x, x finite.  Returns 0 below -87, clamps above 88. */
+AZG_HD float azg_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float magic = 12582912.0f; /* 1.5 * 2^23: round-to-nearest-even of small floats */
+    float kf = AZG_FMAF(x, 1.44269504088896341f, magic);
+    kf = kf - magic;
+    float r = AZG_FMAF(-kf, 0.693145751953125f, x);       /* ln2 hi (12 bits) */
+    r = AZG_FMAF(-kf, 1.42860682030941723212e-6f, r);      /* ln2 lo */
+    float p = 1.98412698412698413e-4f;                     /* 1/5040 */
+    p = AZG_FMAF(p, r, 1.38888888888888894e-3f);           /* 1/720 */
+    p = AZG_FMAF(p, r, 8.33333333333333322e-3f);           /* 1/120 */
+    p = AZG_FMAF(p, r, 4.16666666666666644e-2f);           /* 1/24 */
+    p = AZG_FMAF(p, r, 1.66666666666666657e-1f);           /* 1/6 */
+    p = AZG_FMAF(p, r, 0.5f);
+    p = AZG_FMAF(p, r, 1.0f);
+    p = AZG_FMAF(p, r, 1.0f);
+    int k = (int)kf;
+    return p * azg_u2f((uint32_t)(k + 127) << 23);
+}
+
+/* e^x - 1 */
+AZG_HD float azg_expm1f(float x) {
+    float ax = x < 0.0f ? -x : x;
+    if (ax < 0.35f) {
+        float p = 2.75573192239858925e-6f;                 /* 1/9! */
+        p = AZG_FMAF(p, x, 2.48015873015873016e-5f);       /* 1/8! */
+        p = AZG_FMAF(p, x, 1.98412698412698413e-4f);
+        p = AZG_FMAF(p, x, 1.38888888888888894e-3f);
+        p = AZG_FMAF(p, x, 8.33333333333333322e-3f);
+        p = AZG_FMAF(p, x, 4.16666666666666644e-2f);
+        p = AZG_FMAF(p, x, 1.66666666666666657e-1f);
+        p = AZG_FMAF(p, x, 0.5f);
+        float x2 = x * x;
+        return AZG_FMAF(p, x2, x);
+    }
+    return azg_expf(x) - 1.0f;
+}
+
+/* tanh(z) = sign(z) * em1/(em1+2), em1 = e^{2|z|}-1 */
+AZG_HD float azg_tanhf(float z) {
+    float az = z < 0.0f ? -z : z;
+    float t;
+    if (az > 9.0f) {
+        t = 1.0f;
+    } else {
+        float em1 = azg_expm1f(az + az);
+        t = em1 / (em1 + 2.0f);
+    }
+    return z < 0.0f ? -t : t;
+}
+
+/* ln(x) for x in (0, +inf) normal floats */
+AZG_HD float azg_logf(float x) {
+    uint32_t ix = azg_f2u(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = azg_u2f((ix & 0x007fffffu) | 0x3f800000u);  /* [1,2) */
+    if (m > 1.41421356237309515f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = 1.11111111111111105e-1f;                     /* 1/9 */
+    p = AZG_FMAF(p, z, 1.42857142857142849e-1f);           /* 1/7 */
+    p = AZG_FMAF(p, z, 0.2f);
+    p = AZG_FMAF(p, z, 3.33333333333333315e-1f);
+    p = AZG_FMAF(p, z, 1.0f);
+    float lm = (s + s) * p;
+    return AZG_FMAF((float)e, 0.693147180559945286f, lm);
+}
+
+/* cos(2*pi*u), u in [0,1) */
+AZG_HD float azg_cos2pif(float u) {
+    const float magic = 12582912.0f;
+    float t = u * 4.0f;
+    float qf = (t + magic) - magic;
+    float f = t - qf;                                      /* [-0.5, 0.5], exact */
+    float x = f * 1.57079632679489656f;
+    float z = x * x;
+    float sp = 2.75573192239858925e-6f;                    /* sin: x + x^3 * (...) */
+    sp = AZG_FMAF(sp, z, -1.98412698412698413e-4f);
+    sp = AZG_FMAF(sp, z, 8.33333333333333322e-3f);
+    sp = AZG_FMAF(sp, z, -1.66666666666666657e-1f);
+    float sn = AZG_FMAF(sp * z, x, x);
+    float cp = 2.48015873015873016e-5f;                    /* cos: 1 - z/2 + ... */
+    cp = AZG_FMAF(cp, z, -1.38888888888888894e-3f);
+    cp = AZG_FMAF(cp, z, 4.16666666666666644e-2f);
+    cp = AZG_FMAF(cp, z, -0.5f);
+    float cs = AZG_FMAF(cp, z, 1.0f);
+    int q = ((int)qf) & 3;
+    return q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
+}
+
+/* ---------------------------------------------------------------- float64 */
+
+/* sin and cos of x, |x| < ~1e5 */
+AZG_HD void azg_sincos(double x, double* sn, double* cs) {
+    const double magic = 6755399441055744.0; /* 1.5 * 2^52 */
+    double nf = AZG_FMA(x, 6.36619772367581382433e-01, magic);
+    nf = nf - magic;
+    double r = AZG_FMA(-nf, 1.57079632679489655800e+00, x);
+    r = AZG_FMA(-nf, 6.12323399573676603587e-17, r);
+    r = AZG_FMA(-nf, -1.49738490485919833842e-33, r);
+    double z = r * r;
+    /* fdlibm minimax kernels on [-pi/4, pi/4] */
+    double ps = 1.58969099521155010221e-10;
+    ps = AZG_FMA(ps, z, -2.50507602534068634195e-08);
+    ps = AZG_FMA(ps, z, 2.75573137070700676789e-06);
+    ps = AZG_FMA(ps, z, -1.98412698298579493134e-04);
+    ps = AZG_FMA(ps, z, 8.33333333332248946124e-03);
+    ps = AZG_FMA(ps, z, -1.66666666666666324348e-01);
+    double s = AZG_FMA(ps * z, r, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = AZG_FMA(pc, z, 2.08757232129817482790e-09);
+    pc = AZG_FMA(pc, z, -2.75573143513906633035e-07);
+    pc = AZG_FMA(pc, z, 2.48015872894767294178e-05);
+    pc = AZG_FMA(pc, z, -1.38888888888741095749e-03);
+    pc = AZG_FMA(pc, z, 4.16666666666666019037e-02);
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    double c = w + (((1.0 - w) - hz) + (z * z) * pc);
+    long long n = (long long)nf;
+    int q = (int)(n & 3);
+    *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+    *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+
+/* Python/NumPy float `x % y` for y > 0 and |x/y| < 2^20: exact, result in [0, y). */
+AZG_HD double azg_pymod(double x, double y) {
+    double q = x / y;
+    double qt = (double)(long long)q; /* trunc */
+    double r = AZG_FMA(-qt, y, x);
+    if (r < 0.0) r = r + y;
+    if (r >= y) r = r - y;
+    if (r < 0.0) r = r + y;
+    return r;
+}
+
+/* ---------------------------------------------------------------- RNG */
+
+typedef struct { uint32_t v[4]; } azg_u32x4;
+
+AZG_HD void azg_mulhilo(uint32_t a, uint32_t b, uint32_t* hi, uint32_t* lo) {
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    *hi = (uint32_t)(p >> 32);
+    *lo = (uint32_t)p;
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11) */
+AZG_HD azg_u32x4 azg_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0, lo0, hi1, lo1;
+        azg_mulhilo(0xD2511F53u, c0, &hi0, &lo0);
+        azg_mulhilo(0xCD9E8D57u, c2, &hi1, &lo1);
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    azg_u32x4 r;
+    r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+    return r;
+}
+
+/* uniform in (0,1) with 24 bits: (x>>8 + 0.5) * 2^-24 */
+AZG_HD float azg_u01(uint32_t x) {
+    return AZG_FMAF((float)(x >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);
+}
+
+#define AZG_STREAM_PW 0u      /* progressive-widening action noise, N(0,1) */
+#define AZG_STREAM_EPS 1u     /* epsilon-greedy: v[0] -> u, v[1] -> random child */
+#define AZG_STREAM_ROOT 2u    /* synthetic root states (bench / self-play resets) */
+
+/* the engine's draw #`draw` of stream `stream` for (global tree id, search index) */
+AZG_HD azg_u32x4 azg_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, uint32_t stream) {
+    return azg_philox4x32(tree, search, draw, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+/* standard normal (Box-Muller, cosine branch) */
+AZG_HD float azg_normal(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw) {
+    azg_u32x4 b = azg_draw(seed, tree, search, draw, AZG_STREAM_PW);
+    float u1 = azg_u01(b.v[0]);
+    float u2 = azg_u01(b.v[1]);
+    float r = __builtin_sqrtf(-2.0f * azg_logf(u1));
+    return r * azg_cos2pif(u2);
+}
+
+#endif /* AZG_MATH_H */

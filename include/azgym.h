@@ -1,0 +1,144 @@
+/*
+ * azgym.h -- C ABI of the MI355X batched MCTS engine (libazgym_hip.so).
+ *
+ * The reference (timoklein/alphazero-gym, pure Python) has no FFI; its boundary for the
+ * hot path is the Python class surface MCTSDiscrete / MCTSContinuous (alphazero/search/mcts.py)
+ * called from DiscreteAgent.act / ContinuousAgent.act (alphazero/agent/agents.py:257-303, 492-537).
+ * Each entry point below replaces one piece of that surface for B independent trees at once; the
+ * ctypes facade in alphazero_gym_amd/search/mcts.py binds exactly these symbols.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every in/out buffer (host memory),
+ * the engine copies in/out and never retains caller pointers; the engine owns all device memory.
+ * Return 0 on success, a negative AZG_E_* code otherwise, message via azg_last_error().
+ * An engine is single-owner and not re-entrant: one engine per GPU per process.
+ *
+ * The CPU oracle (oracle/azg_oracle.c, test infrastructure only) exports the same functions with
+ * the prefix azo_ instead of azg_ and the same structs, so tests drive both with identical inputs.
+ */
+#ifndef AZGYM_H
+#define AZGYM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZG_ABI_VERSION 1
+
+enum { AZG_OK = 0, AZG_E_INVALID = -1, AZG_E_TERMINAL_ROOT = -2, AZG_E_DEVICE = -3, AZG_E_STATE = -4, AZG_E_UNSUPPORTED = -5 };
+
+/* closed-form environments (gym classic control; call sites alphazero/search/mcts.py:443-449, 680-687) */
+enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2 };
+/* MCTSDiscrete (mcts.py:310-526) / MCTSContinuous (mcts.py:529-741) */
+enum { AZG_MODE_DISCRETE = 0, AZG_MODE_CONTINUOUS = 1 };
+/* V_target_policy (mcts.py:299-304) */
+enum { AZG_VT_OFF_POLICY = 0, AZG_VT_ON_POLICY = 1, AZG_VT_GREEDY = 2 };
+/* trunk nonlinearity (alphazero/network/utils.py:5-14; configs use relu and elu) */
+enum { AZG_ACT_RELU = 0, AZG_ACT_ELU = 1 };
+
+#define AZG_MAX_HIDDEN_LAYERS 8
+
+/* Constructor kwargs of MCTSDiscrete.__init__ (mcts.py:316-362) / MCTSContinuous.__init__ (mcts.py:537-587),
+ * plus the batch geometry. */
+typedef struct azg_config {
+    int32_t struct_size;   /* sizeof(azg_config), checked */
+    int32_t device_id;     /* HIP device ordinal */
+    int32_t env_id;        /* AZG_ENV_* */
+    int32_t mode;          /* AZG_MODE_* */
+    int32_t n_trees;       /* B: independent trees searched by one azg_search call */
+    int32_t n_sims;        /* n_rollouts */
+    int32_t num_actions;   /* discrete only */
+    int32_t v_target;      /* AZG_VT_* */
+    int32_t tree_id_base;  /* global id of local tree 0 (multi-GPU sharding; keys the RNG streams) */
+    int32_t reserved0;
+    double c_uct;
+    double gamma;
+    double epsilon;
+    double c_pw;           /* continuous only */
+    double kappa;          /* continuous only */
+    double reward_scale;   /* continuous only: PENDULUM_R_SCALE (mcts.py:20, 687); reward /= reward_scale */
+    double action_bound;   /* continuous only: squashed-Normal bound (policies.py:493-499) */
+    uint64_t seed;
+} azg_config;
+
+/* Policy/value MLP: trunk of n_hidden Linear+activation layers, value head Linear(H,1), distribution head
+ * Linear(H, n_dist) with n_dist = num_actions (DiscretePolicy, policies.py:238-259) or 2*action_dim
+ * (DiagonalNormalPolicy, policies.py:434).  Weight blob = torch state_dict order and layout:
+ * for each trunk layer W[out][in] then b[out]; value_head W[1][H], b[1]; dist_head W[n_dist][H], b[n_dist]. */
+typedef struct azg_mlp_desc {
+    int32_t struct_size;
+    int32_t in_dim;
+    int32_t n_hidden;
+    int32_t hidden[AZG_MAX_HIDDEN_LAYERS];
+    int32_t n_dist;
+    int32_t activation;    /* AZG_ACT_* */
+    float log_std_min;     /* clamp of log_std (policies.py:456-460); continuous only */
+    float log_std_max;
+} azg_mlp_desc;
+
+typedef struct azg_engine azg_engine;
+
+int azg_abi_version(void);
+
+/* MCTS*.__init__ */
+int azg_engine_create(const azg_config* cfg, azg_engine** out);
+void azg_engine_destroy(azg_engine* e);
+const char* azg_last_error(const azg_engine* e); /* e may be NULL: last create error */
+
+/* model=self.nn (agents.py:82): copies and re-lays-out the weights; call again after every optimiser step */
+int azg_set_weights(azg_engine* e, const azg_mlp_desc* desc, const float* blob, size_t n_floats);
+
+/* index mixed into the RNG counter; auto-incremented by azg_search */
+int azg_set_search_index(azg_engine* e, uint32_t idx);
+
+/* MCTS*.search(Env) (mcts.py:418-462, 656-702) for B trees.
+ *   root_env_state [B][S_env] float64: CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot)
+ *   root_n_carry   [B] or NULL: visit count carried by a reused root (MCTSDiscrete.forward, mcts.py:495-526)
+ * Terminal roots -> AZG_E_TERMINAL_ROOT (ValueError at mcts.py:382-383, 599-600). */
+int azg_search(azg_engine* e, const double* root_env_state, const int32_t* root_n_carry);
+
+/* MCTS.return_results (mcts.py:269-307): root statistics, rows padded to azg_max_children().
+ *   actions [B][Kmax] float32 (discrete: the action index as float), counts [B][Kmax] int32,
+ *   Q [B][Kmax] float64, v_target [B] float64, n_children [B] int32.  Any pointer may be NULL. */
+int azg_results(azg_engine* e, float* actions, int32_t* counts, double* Q, double* v_target, int32_t* n_children);
+
+/* What MCTSDiscrete.forward (mcts.py:495-526) inspects: per root child the child node's visit count
+ * (-1: edge has no child node) and its environment state.  child_n [B][Kmax], child_state [B][Kmax][S_env]. */
+int azg_root_children(azg_engine* e, int32_t* child_n, double* child_state);
+
+/* root network outputs cached by the search: value [B] float32; dist [B][n_dist] float32
+ * (continuous: mu.., sigma..; discrete: softmax priors). For MLP parity tests. */
+int azg_root_eval(azg_engine* e, float* value, float* dist);
+
+/* whole-tree dump for bit-exact parity tests: per tree the node/edge records in creation order.
+ * See DESIGN.md "record layout". rec_* arrays are [B][azg_max_records()]; n_records [B]. */
+int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* edge_n, double* edge_W, double* edge_Q,
+                  float* edge_action, int32_t* node_n, double* node_r, float* node_V, uint8_t* node_flags);
+
+int azg_max_children(const azg_engine* e);
+int azg_max_records(const azg_engine* e);
+int azg_env_state_dim(const azg_engine* e);
+int azg_obs_dim(const azg_engine* e);
+
+/* synthetic fixed-seed root states for benchmarks and self-play resets:
+ * Pendulum theta~U(-pi,pi), theta_dot~U(-1,1); CartPole ~U(-0.05,0.05)^4, keyed by global tree id. */
+int azg_synthetic_roots(azg_engine* e, double* root_env_state /*[B][S_env]*/);
+
+/* timing of the last azg_search measured with HIP events on the engine stream (kernel only), milliseconds */
+int azg_last_search_ms(azg_engine* e, float* ms);
+
+/* device-resident variant used by bench.py: roots already uploaded by a previous azg_search/azg_upload_roots;
+ * runs the search kernel only (no host<->device copies) */
+int azg_upload_roots(azg_engine* e, const double* root_env_state, const int32_t* root_n_carry);
+int azg_search_resident(azg_engine* e);
+int azg_sync(azg_engine* e);
+
+/* bit-exactness self test of azg_math.h on the device: evaluates fn_id on n inputs */
+int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZGYM_H */

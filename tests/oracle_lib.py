@@ -1,0 +1,128 @@
+"""Loader for the CPU oracle (oracle/libazg_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from alphazero_gym_amd import _capi  # noqa: E402
+
+LIB_PATH = os.path.join(ROOT, "oracle", "libazg_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(ROOT, "oracle", "azg_oracle.c")
+    hdr = os.path.join(ROOT, "include", "azg_math.h")
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "-s"])
+    return LIB_PATH
+
+
+_lib = None
+_fns = None
+
+
+def lib():
+    global _lib, _fns
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _fns = _capi.bind(_lib, "azo_")
+        _lib.azo_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.azo_normal.restype = C.c_float
+        _lib.azo_eps_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        _lib.azo_eps_draw.restype = None
+        _lib.azo_sample_action.argtypes = [C.c_float] * 4
+        _lib.azo_sample_action.restype = C.c_float
+        _lib.azo_math_eval.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
+        _lib.azo_mlp_eval.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.azo_env_step.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        _lib.azo_env_obs.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    return _lib
+
+
+def fns():
+    lib()
+    return _fns
+
+
+class OracleEngine(_capi.Engine):
+    def __init__(self, **kw):
+        super().__init__(fns(), **kw)
+
+    def mlp_eval(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1, self.s_obs)
+        n = obs.shape[0]
+        value = np.empty((n,), np.float32)
+        dist = np.empty((n, self.n_dist), np.float32)
+        raw = np.empty((n, 1 + self.n_dist), np.float32)
+        rc = lib().azo_mlp_eval(self._h, _capi._ptr(obs, C.c_float), n, _capi._ptr(value, C.c_float),
+                                _capi._ptr(dist, C.c_float), _capi._ptr(raw, C.c_float))
+        assert rc == 0, rc
+        return value, dist, raw
+
+
+def normal(seed, tree, search, draw):
+    return float(lib().azo_normal(seed, tree, search, draw))
+
+
+def eps_draw(seed, tree, search, draw):
+    u = C.c_float()
+    r = C.c_uint32()
+    lib().azo_eps_draw(seed, tree, search, draw, C.byref(u), C.byref(r))
+    return float(u.value), int(r.value)
+
+
+def sample_action(mu, sigma, eps, bound):
+    return np.float32(lib().azo_sample_action(float(mu), float(sigma), float(eps), float(bound)))
+
+
+def math_eval(fn_id, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    rc = lib().azo_math_eval(fn_id, _capi._ptr(x, C.c_double), _capi._ptr(out, C.c_double), x.size)
+    assert rc == 0
+    return out
+
+
+def env_step(env_id, state, action):
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    nxt = np.empty_like(state)
+    r = C.c_double()
+    d = C.c_int32()
+    obs = np.empty((4 if env_id == 0 else 3,), np.float32)
+    rc = lib().azo_env_step(env_id, _capi._ptr(state, C.c_double), float(action), _capi._ptr(nxt, C.c_double), C.byref(r),
+                            C.byref(d), _capi._ptr(obs, C.c_float))
+    assert rc == 0
+    return nxt, r.value, bool(d.value), obs
+
+
+def make_weights(seed, in_dim, hidden, n_dist, scale=1.0):
+    """Deterministic synthetic weights, torch nn.Linear default-init ranges (U(-1/sqrt(fan_in), 1/sqrt(fan_in))),
+    drawn from numpy's PCG64 so that fixtures only need to store the seed."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    k = in_dim
+    for h in list(hidden):
+        b = 1.0 / np.sqrt(k)
+        parts.append(rng.uniform(-b, b, size=(h, k)).astype(np.float32).ravel() * np.float32(scale))
+        parts.append(rng.uniform(-b, b, size=(h,)).astype(np.float32))
+        k = h
+    b = 1.0 / np.sqrt(k)
+    parts.append(rng.uniform(-b, b, size=(1, k)).astype(np.float32).ravel())
+    parts.append(rng.uniform(-b, b, size=(1,)).astype(np.float32))
+    parts.append(rng.uniform(-b, b, size=(n_dist, k)).astype(np.float32).ravel() * np.float32(scale))
+    parts.append(rng.uniform(-b, b, size=(n_dist,)).astype(np.float32))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)

@@ -1,0 +1,97 @@
+"""Shared helpers for the parity tests: rebuild an engine from a golden case, compare tree dumps."""
+import ast
+import os
+
+import numpy as np
+
+import oracle_lib as O
+from alphazero_gym_amd import _capi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+T1_NAMES = [
+    "t1_pendulum_v1_default", "t1_pendulum_v0_gamma", "t1_pendulum_v1_epsgreedy", "t1_cartpole_default",
+    "t1_cartpole_epsgreedy", "t1_cartpole_explore", "t1_cartpole_reuse",
+]
+
+DUMP_INT = ("n_records", "parent", "edge_n", "node_n", "node_flags")
+DUMP_F32 = ("edge_action", "node_V")
+DUMP_F64 = ("edge_W", "edge_Q", "node_r")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = ast.literal_eval(str(z["case"]))
+    return case, z
+
+
+def engine_kwargs(case, n_trees, tree_id_base=None):
+    return dict(env_id=case["env_id"], mode=case["mode"], n_trees=n_trees, n_sims=case["n_sims"], c_uct=case["c_uct"],
+                gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0), c_pw=case.get("c_pw", 1.0),
+                kappa=case.get("kappa", 0.5), v_target=case["v_target"], action_bound=case.get("action_bound", 2.0),
+                seed=case["seed"], tree_id_base=case.get("tree_id_base", 0) if tree_id_base is None else tree_id_base)
+
+
+def case_weights(case):
+    cont = case["mode"] == 1
+    in_dim = 3 if cont else 4
+    n_dist = 2 if cont else case["num_actions"]
+    blob = O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0))
+    return _capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]), blob
+
+
+def run_case(engine_cls, case, z):
+    """Replay a golden T1 case on an engine class; returns a list of (results, dump, child_n) per golden row."""
+    n_roots = len(case["roots"])
+    steps = case.get("reuse_steps", 1)
+    rows = z["root_state"].shape[0]
+    out = []
+    if steps == 1:
+        eng = engine_cls(**engine_kwargs(case, n_roots))
+        eng.set_weights(*case_weights(case))
+        eng.set_search_index(case.get("search_idx", 0))
+        eng.search(z["root_state"], z["carry_in"])
+        res, dump = eng.results(), eng.dump_tree()
+        cn, _ = eng.root_children()
+        for i in range(n_roots):
+            out.append(({k: v[i] for k, v in res.items()}, {k: v[i] for k, v in dump.items()}, cn[i]))
+        eng.close()
+    else:
+        # tree reuse (MCTSDiscrete.forward): one single-tree engine per root, successive searches with the carried root count
+        per_tree = rows // n_roots
+        for ti in range(n_roots):
+            eng = engine_cls(**engine_kwargs(case, 1, tree_id_base=case.get("tree_id_base", 0) + ti))
+            eng.set_weights(*case_weights(case))
+            for s in range(per_tree):
+                row = ti * per_tree + s
+                eng.set_search_index(case.get("search_idx", 0) + s)
+                eng.search(z["root_state"][row:row + 1], z["carry_in"][row:row + 1])
+                res, dump = eng.results(), eng.dump_tree()
+                cn, _ = eng.root_children()
+                out.append(({k: v[0] for k, v in res.items()}, {k: v[0] for k, v in dump.items()}, cn[0]))
+            eng.close()
+    return out
+
+
+def compare_rows(out, z, float_tol=0.0, check_v_target=True):
+    """Assert engine rows == golden rows.  Integers exactly; floats exactly when float_tol == 0."""
+    for row, (res, dump, cn) in enumerate(out):
+        nc = int(z["n_children"][row])
+        assert int(res["n_children"]) == nc, (row, res["n_children"], nc)
+        np.testing.assert_array_equal(res["counts"][:nc], z["counts"][row][:nc], err_msg=f"row {row} counts")
+        for k in DUMP_INT:
+            np.testing.assert_array_equal(dump[k], z[k][row], err_msg=f"row {row} {k}")
+        np.testing.assert_array_equal(cn[:nc], z["child_n"][row][:nc], err_msg=f"row {row} child_n")
+        for k in DUMP_F32 + DUMP_F64:
+            if float_tol == 0.0:
+                np.testing.assert_array_equal(dump[k], z[k][row], err_msg=f"row {row} {k}")
+            else:
+                np.testing.assert_allclose(dump[k], z[k][row], rtol=float_tol, atol=float_tol, err_msg=f"row {row} {k}")
+        if float_tol == 0.0:
+            np.testing.assert_array_equal(res["actions"][:nc], z["actions"][row][:nc])
+            np.testing.assert_array_equal(res["Q"][:nc], z["Q"][row][:nc])
+        else:
+            np.testing.assert_allclose(res["actions"][:nc], z["actions"][row][:nc], rtol=float_tol, atol=float_tol)
+            np.testing.assert_allclose(res["Q"][:nc], z["Q"][row][:nc], rtol=float_tol, atol=float_tol)
+        if check_v_target:
+            np.testing.assert_allclose(res["v_target"], z["v_target"][row], rtol=1e-12, atol=1e-12)
