@@ -1,0 +1,1120 @@
+// azg_engine.hip -- MI355X (gfx950) batched MCTS engine behind the C ABI of include/azgym.h.
+//
+// One persistent kernel launch runs a whole MCTS search (all n_sims simulations) for B independent trees.
+//   * workgroup = 256 threads = 4 waves = one group of 16 trees (= one 16-row MFMA tile of leaf evaluations);
+//     a workgroup never talks to another one, so there is no grid-wide synchronisation anywhere.
+//   * tree phase: a 16-lane sub-wave owns one tree.  Lanes scan the <=16 children of a node in parallel
+//     (PUCT / progressive-widening UCT, float64), arg-max by a 4-step butterfly, step the closed-form
+//     environment, expand, and back the return up the path.
+//   * network phase: the policy/value MLP for the 16 new leaves on v_mfma_f32_16x16x4_f32.  Activations are
+//     kept transposed ([unit][tree]) so that an MFMA's D registers are the next layer's B operand as they
+//     stand; hidden->hidden weights can live in the 512-entry VGPR/AGPR file for the whole search (NREG>0).
+// Reference semantics: alphazero/search/mcts.py (search 418-462 / 656-702, selectionUCT 464-493 / 704-741,
+// backprop 241-267, return_results 269-307), alphazero/search/states.py, alphazero/network/policies.py.
+// The arithmetic (operation order, float32/float64 placement) is specified by oracle/azg_oracle.c, which is pinned
+// to the reference by tests/golden; this file must agree with it bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/azg_math.h"
+#include "../../include/azgym.h"
+
+#define FLAG_EXPANDED 1
+#define FLAG_TERMINAL 2
+#define TREES_PER_WG 16
+#define MAX_STREAM_LAYERS 8
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 32-byte "hot" record: everything selection and backup touch.  Record j = edge j + (once expanded) its child node.
+struct __attribute__((aligned(16))) Hot {
+    double Q;               // edge action value (Q_init = parent V)
+    double W;               // edge cumulative return
+    int edge_n;             // edge visit count
+    int node_n;             // node visit count
+    short parent;           // record of the parent node, -1 for the root
+    unsigned short n_child; // node: number of child edges
+    unsigned char flags;    // FLAG_EXPANDED | FLAG_TERMINAL
+    unsigned char pad[3];
+};
+static_assert(sizeof(Hot) == 32, "Hot must be 32 bytes");
+
+struct KParams {
+    int B, n_sims, R, Kp, A, nd, n_out, n_hidden, act, v1, tree_base, mode;
+    double c_uct, gamma, epsilon, reward_scale;
+    float c_uct_f, gamma_f, bound_f, ls_min, ls_max;
+    unsigned long long seed;
+    unsigned search_idx;
+    int S;                   // env state dim
+    int tab_n;               // entries in sqrt_tab
+    const double* roots;     // [B][S]
+    const int* carry;        // [B]
+    Hot* hot;                // [B][R]
+    double* node_r;          // [B][R]
+    float* node_V;           // [B][R]
+    float* action;           // [B][R]
+    float* dist;             // [B][R][nd]
+    double* state;           // [B][R][S]
+    unsigned short* child;   // [B][R][Kp]
+    int* n_rec;              // [B]
+    const int* pw_need;      // [n_sims+2]
+    const double* sqrt_tab;  // [tab_n]  sqrt(n+1)
+    const float* W0;         // [HP/16][64]
+    const f32x4* b0;         // [HP/16][64]
+    const f32x4* Wl[MAX_STREAM_LAYERS]; // hidden->hidden layer l (1-based index l-1): [HP/16 tiles][HP/16 s4][64]
+    const f32x4* bl[MAX_STREAM_LAYERS]; // [HP/16][64]
+    const f32x4* Whead;      // [HP/16 s4][64]
+    const float* bhead;      // [16]
+};
+
+// ------------------------------------------------------------------------------------------------ environments
+
+template <int ENV>
+__device__ __forceinline__ void env_obs(const double* s, float* obs) {
+    if (ENV == AZG_ENV_CARTPOLE) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
+    } else {
+        double sn, cs;
+        azg_sincos(s[0], &sn, &cs);
+        obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1]; obs[3] = 0.0f;
+    }
+}
+
+// gym CartPoleEnv.step (explicit Euler); same operation order as oracle/azg_oracle.c cartpole_step
+__device__ __forceinline__ void cartpole_step(const double* s, int action, double* o, double* reward, int* done) {
+    const double gravity = 9.8, masspole = 0.1, total_mass = 0.1 + 1.0, length = 0.5;
+    const double polemass_length = 0.1 * 0.5, force_mag = 10.0, tau = 0.02;
+    const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
+    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    double force = action == 1 ? force_mag : -force_mag;
+    double sintheta, costheta;
+    azg_sincos(theta, &sintheta, &costheta);
+    double temp = (force + (polemass_length * (theta_dot * theta_dot)) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - (masspole * (costheta * costheta)) / total_mass));
+    double xacc = temp - ((polemass_length * thetaacc) * costheta) / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    o[0] = x; o[1] = x_dot; o[2] = theta; o[3] = theta_dot;
+    *done = (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);
+    *reward = 1.0;
+}
+
+// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after
+__device__ __forceinline__ void pendulum_step(int v1, const double* s, float action, double* o, double* reward, int* done) {
+    const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
+    const float max_torque = 2.0f;
+    double th = s[0], thdot = s[1];
+    float uc = action < -max_torque ? -max_torque : (action > max_torque ? max_torque : action);
+    double u = (double)uc;
+    double an = azg_pymod(th + pi, 2.0 * pi) - pi;
+    double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
+    double newth, newthdot, sn, cs;
+    if (v1) {
+        azg_sincos(th, &sn, &cs);
+        newthdot = thdot + (15.0 * sn + 3.0 * u) * dt;
+        newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+        newth = th + newthdot * dt;
+    } else {
+        azg_sincos(th + pi, &sn, &cs);
+        newthdot = thdot + (-15.0 * sn + 3.0 * u) * dt;
+        newth = th + newthdot * dt;
+        newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+    }
+    o[0] = newth; o[1] = newthdot;
+    *reward = -costs;
+    *done = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ MLP on MFMA
+
+__device__ __forceinline__ float act_fn(int act, float x) {
+    if (act == AZG_ACT_ELU) return x > 0.0f ? x : azg_expm1f(x);
+    return x > 0.0f ? x : 0.0f;
+}
+
+__device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
+    f32x4 r;
+    r.x = act_fn(act, v.x); r.y = act_fn(act, v.y); r.z = act_fn(act, v.z); r.w = act_fn(act, v.w);
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+// Register-resident hidden->hidden weights: wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer.
+template <int HP, int NREG>
+struct WRegs {
+    static constexpr int NTW = HP / 64;
+    static constexpr int S4 = HP / 16;
+    f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
+    f32x4 b[NREG > 0 ? NREG : 1][NTW];
+    f32x4 wh[NTW];   // head weights of this wave's K-chunk
+};
+
+// The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  outs: [16 trees][16 outputs].
+// Activations: act buffers of HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand.
+template <int HP, int NREG>
+__device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
+                                            f32x4* parts, float* outs, int wave, int lane) {
+    constexpr int NTW = HP / 64;   // output tiles per wave
+    constexpr int S4 = HP / 16;    // groups of 4 MFMA k-steps over a hidden vector
+    // layer 0: K = in_dim <= 4 -> one k-step
+    {
+        float b = obsT[lane];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            int nt = wave * NTW + i;
+            f32x4 acc = P.b0[nt * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, acc, 0, 0, 0);
+            actA[nt * 64 + lane] = act4(P.act, acc);
+        }
+    }
+    __syncthreads();
+    f32x4* in = actA;
+    f32x4* out = actB;
+    // hidden->hidden layers held in registers
+    if (NREG > 0) {
+#pragma unroll
+        for (int l = 0; l < NREG; ++l) {
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = wr.b[l][i];
+#pragma unroll
+            for (int s4 = 0; s4 < S4; ++s4) {
+                f32x4 b = in[s4 * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = mfma4(wr.w[l][i][s4], b, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
+            __syncthreads();
+            f32x4* t = in; in = out; out = t;
+        }
+    } else {
+        // weights streamed from global memory (L2-resident), any number of layers
+        for (int l = 1; l < P.n_hidden; ++l) {
+            const f32x4* W = P.Wl[l - 1];
+            const f32x4* bb = P.bl[l - 1];
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = bb[(wave * NTW + i) * 64 + lane];
+#pragma unroll 4
+            for (int s4 = 0; s4 < S4; ++s4) {
+                f32x4 b = in[s4 * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    f32x4 a = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
+                    acc[i] = mfma4(a, b, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
+            __syncthreads();
+            f32x4* t = in; in = out; out = t;
+        }
+    }
+    // heads: wave w sums its quarter of the hidden units (chain from 0), partials combined in fixed order
+    {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            int s4 = wave * NTW + i;
+            f32x4 a = (NREG > 0) ? wr.wh[i] : P.Whead[s4 * 64 + lane];
+            acc = mfma4(a, in[s4 * 64 + lane], acc);
+        }
+        parts[wave * 64 + lane] = acc;
+    }
+    __syncthreads();
+    {
+        int tid = wave * 64 + lane;
+        int tree = tid & 15, o = tid >> 4;
+        if (o < P.n_out) {
+            float total = P.bhead[o];
+            int idx = (o >> 2) * 16 + tree;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x4 pv = parts[w * 64 + idx];
+                float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
+                total = total + p;
+            }
+            outs[tree * 16 + o] = total;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
+
+// lane index (0..15) of the maximum, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
+__device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
+    double bu = valid ? u : -__builtin_huge_val();
+    int bi = valid ? sub : 99;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        double ou = __shfl_xor(bu, m, 16);
+        int oi = __shfl_xor(bi, m, 16);
+        if (ou > bu || (ou == bu && oi < bi)) { bu = ou; bi = oi; }
+    }
+    return bi;
+}
+
+template <int ENV, int HP, int NREG>
+__global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr int S = CONT ? 2 : 4;
+    __shared__ f32x4 s_actA[HP / 16 * 64];
+    __shared__ f32x4 s_actB[HP / 16 * 64];
+    __shared__ f32x4 s_parts[4 * 64];
+    __shared__ float s_obsT[4 * 16];
+    __shared__ float s_outs[16 * 16];
+    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n] then pw_need [n_sims+2] (ints)
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sub = lane & 15;
+    const int tl = wave * 4 + (lane >> 4);          // tree within the workgroup
+    const int tree = blockIdx.x * TREES_PER_WG + tl;
+    const bool live = tree < P.B;
+    const unsigned gtree = (unsigned)(P.tree_base + tree);
+
+    double* s_sqrt = s_dyn;
+    int* s_pw = (int*)(s_dyn + P.tab_n);
+    for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
+    if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
+
+    // register-resident weights
+    WRegs<HP, NREG> wr;
+    if (NREG > 0) {
+        constexpr int NTW = HP / 64, S4 = HP / 16;
+#pragma unroll
+        for (int l = 0; l < NREG; ++l) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                wr.b[l][i] = P.bl[l][(wave * NTW + i) * 64 + lane];
+#pragma unroll
+                for (int s4 = 0; s4 < S4; ++s4) wr.w[l][i][s4] = P.Wl[l][((wave * NTW + i) * S4 + s4) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) wr.wh[i] = P.Whead[(wave * NTW + i) * 64 + lane];
+    }
+
+    const size_t tb = (size_t)(live ? tree : 0) * P.R;
+    Hot* hot = P.hot + tb;
+    double* node_r = P.node_r + tb;
+    float* node_V = P.node_V + tb;
+    float* action = P.action + tb;
+    float* dist = P.dist + tb * P.nd;
+    double* state = P.state + tb * S;
+    unsigned short* child = P.child + tb * P.Kp;
+
+    int nrec = 1;
+    unsigned eps_draws = 0;
+    int leaf = 0;
+    bool need_eval = live;
+
+    // ---- root (initialize_search + evaluation / add_value_estimate: mcts.py:364-383, 437; 589-600, 672)
+    {
+        double rs[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) rs[k] = live ? P.roots[(size_t)tree * S + k] : 0.0;
+        float obs[4];
+        env_obs<ENV>(rs, obs);
+        if (live && sub == 0) {
+            Hot h;
+            h.Q = 0.0; h.W = 0.0; h.edge_n = 0; h.node_n = P.carry[tree]; h.parent = -1; h.n_child = 0;
+            h.flags = FLAG_EXPANDED; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+            hot[0] = h;
+            node_r[0] = 0.0;
+            action[0] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < S; ++k) state[k] = rs[k];
+        }
+        if (sub < 4) s_obsT[sub * 16 + tl] = live ? obs[sub] : 0.0f;
+    }
+    __syncthreads();
+
+    for (int sim = -1; sim < P.n_sims; ++sim) {
+        // ================= network phase: evaluate the 16 pending leaves =================
+        int any = __syncthreads_or(need_eval ? 1 : 0);
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, wave, lane);
+
+        // ================= tree phase A: finish the evaluated leaf, back up =================
+        if (live) {
+            float V = 0.0f;
+            if (need_eval) {
+                V = s_outs[tl * 16 + 0];
+                if (CONT) {
+                    float mu = s_outs[tl * 16 + 1];
+                    float ls = s_outs[tl * 16 + 2];
+                    ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
+                    float sg = azg_expf(ls);
+                    if (sub == 0) { node_V[leaf] = V; dist[leaf * 2] = mu; dist[leaf * 2 + 1] = sg; }
+                } else {
+                    // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
+                    const int A = P.A;
+                    float mx = s_outs[tl * 16 + 1];
+                    for (int a = 1; a < A; ++a) { float v = s_outs[tl * 16 + 1 + a]; mx = v > mx ? v : mx; }
+                    float sum = 0.0f;
+                    for (int a = 0; a < A; ++a) sum = sum + azg_expf(s_outs[tl * 16 + 1 + a] - mx);
+                    int k0 = nrec;
+                    nrec += A;
+                    if (sub < A) {
+                        float pr = azg_expf(s_outs[tl * 16 + 1 + sub] - mx) / sum;
+                        dist[leaf * P.nd + sub] = pr;
+                        Hot h;
+                        h.Q = (double)V; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = (short)leaf; h.n_child = 0;
+                        h.flags = 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+                        hot[k0 + sub] = h;
+                        action[k0 + sub] = (float)sub;
+                        child[leaf * P.Kp + sub] = (unsigned short)(k0 + sub);
+                    }
+                    if (sub == 0) { node_V[leaf] = V; hot[leaf].n_child = (unsigned short)A; }
+                }
+            } else if (sim >= 0) {
+                V = node_V[leaf];
+            }
+            if (sim >= 0) {
+                // MCTS.backprop (mcts.py:260-267); all 16 lanes walk redundantly, lane 0 stores
+                int j = leaf;
+                bool first = true;
+                double Rv = 0.0;
+                Hot hj = hot[j];
+                while (hj.parent >= 0) {
+                    double gR;
+                    if (first) {
+                        gR = CONT ? (double)(P.gamma_f * V) : P.gamma * (double)V;
+                        first = false;
+                    } else {
+                        gR = P.gamma * Rv;
+                    }
+                    Rv = node_r[j] + gR;
+                    int en = hj.edge_n + 1;
+                    double W = hj.W + Rv;
+                    double Q = W / (double)en;
+                    if (sub == 0) { hot[j].Q = Q; hot[j].W = W; hot[j].edge_n = en; }
+                    j = hj.parent;
+                    hj = hot[j];
+                    if (sub == 0) hot[j].node_n = hj.node_n + 1;
+                }
+            } else if (CONT) {
+                // add_pw_action(root) before the first trace (mcts.py:673)
+                float mu = s_outs[tl * 16 + 1];
+                float ls = s_outs[tl * 16 + 2];
+                ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
+                float sg = azg_expf(ls);
+                int k = nrec++;
+                float eps = azg_normal(P.seed, gtree, P.search_idx, (unsigned)k);
+                float a = P.bound_f * azg_tanhf(mu + sg * eps);
+                if (sub == 0) {
+                    Hot h;
+                    h.Q = (double)V; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = 0; h.n_child = 0; h.flags = 0;
+                    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+                    hot[k] = h;
+                    action[k] = a;
+                    child[0] = (unsigned short)k;
+                    hot[0].n_child = 1;
+                }
+            }
+        }
+        if (sim == P.n_sims - 1) break;
+        __threadfence_block();
+
+        // ================= tree phase B: next trace: select down, step the env, expand =================
+        need_eval = false;
+        if (live) {
+            int p = 0;
+            while (true) {
+                Hot hp = hot[p];
+                int K = hp.n_child;
+                int chosen;
+                unsigned cflags;
+                float cact;
+                bool widen = false;
+                if (CONT) {
+                    int nn = hp.node_n < P.n_sims + 1 ? hp.node_n : P.n_sims + 1;
+                    widen = s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
+                }
+                if (widen) {
+                    // MCTSContinuous.add_pw_action (mcts.py:625-654)
+                    chosen = nrec++;
+                    float mu = dist[p * 2], sg = dist[p * 2 + 1];
+                    float Vp = node_V[p];
+                    float eps = azg_normal(P.seed, gtree, P.search_idx, (unsigned)chosen);
+                    cact = P.bound_f * azg_tanhf(mu + sg * eps);
+                    cflags = 0;
+                    if (sub == 0) {
+                        Hot h;
+                        h.Q = (double)Vp; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = (short)p; h.n_child = 0; h.flags = 0;
+                        h.pad[0] = h.pad[1] = h.pad[2] = 0;
+                        hot[chosen] = h;
+                        action[chosen] = cact;
+                        child[p * P.Kp + K] = (unsigned short)chosen;
+                        hot[p].n_child = (unsigned short)(K + 1);
+                    }
+                } else {
+                    int pick = -1;
+                    if (P.epsilon != 0.0) {
+                        // MCTS.epsilon_greedy (mcts.py:190-195)
+                        azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, eps_draws++, AZG_STREAM_EPS);
+                        if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
+                    }
+                    double sq = s_sqrt[hp.node_n];
+                    int c = 0;
+                    unsigned fl = 0;
+                    double U = 0.0;
+                    // children are scanned 16 at a time
+                    int win_c = 0;
+                    unsigned win_f = 0;
+                    double win_u = 0.0;
+                    bool have = false;
+                    for (int base = 0; base < K; base += 16) {
+                        int i = base + sub;
+                        bool valid = i < K;
+                        if (valid) {
+                            c = child[p * P.Kp + i];
+                            Hot hc = hot[c];
+                            fl = hc.flags;
+                            double ratio = sq / (double)(hc.edge_n + 1);
+                            if (CONT) {
+                                U = hc.Q + P.c_uct * ratio;
+                            } else {
+                                float pc = dist[p * P.nd + i] * P.c_uct_f;   // float32 product (NumPy>=2 promotion)
+                                U = hc.Q + (double)pc * ratio;
+                            }
+                        }
+                        int w;
+                        if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
+                        else w = argmax16(U, valid, sub);
+                        if (w >= 0) {
+                            int wc = __shfl(c, w, 16);
+                            unsigned wf = __shfl(fl, w, 16);
+                            double wu = __shfl(U, w, 16);
+                            if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_f = wf; win_u = wu; have = true; }
+                        }
+                    }
+                    chosen = win_c;
+                    cflags = win_f;
+                    cact = 0.0f;
+                }
+                if (cflags & FLAG_EXPANDED) {
+                    p = chosen;
+                    if (cflags & FLAG_TERMINAL) { leaf = p; break; }
+                    continue;
+                }
+                // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
+                double st[S], ns[S], r;
+                int done;
+#pragma unroll
+                for (int k = 0; k < S; ++k) st[k] = state[p * S + k];
+                if (!widen) cact = action[chosen];
+                if (CONT) {
+                    pendulum_step(P.v1, st, cact, ns, &r, &done);
+                    r = r / P.reward_scale;   // mcts.py:687
+                } else {
+                    cartpole_step(st, (int)cact, ns, &r, &done);
+                }
+                float obs[4];
+                env_obs<ENV>(ns, obs);
+                if (sub == 0) {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) state[chosen * S + k] = ns[k];
+                    node_r[chosen] = r;
+                    hot[chosen].node_n = 0;
+                    hot[chosen].n_child = 0;
+                    hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+                    if (done) node_V[chosen] = 0.0f;
+                }
+                leaf = chosen;
+                need_eval = !done;
+                if (sub < 4) s_obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
+                break;
+            }
+        }
+        __threadfence_block();
+    }
+    if (live && sub == 0) P.n_rec[tree] = nrec;
+}
+
+// ------------------------------------------------------------------------------------------------ result gathering
+
+// MCTS.return_results (mcts.py:269-307): one thread per tree
+__global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt, int* nch,
+                               int* child_n, double* child_state, float* root_V, float* root_dist) {
+    int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= P.B) return;
+    size_t tb = (size_t)tree * P.R;
+    const Hot* hot = P.hot + tb;
+    const unsigned short* child = P.child + tb * P.Kp;
+    int nc = hot[0].n_child;
+    long tot = 0;
+    for (int a = 0; a < nc; ++a) tot += hot[child[a]].edge_n;
+    double qmax = 0.0, onp = 0.0;
+    for (int a = 0; a < Kmax; ++a) {
+        int k = a < nc ? child[a] : -1;
+        Hot h;
+        if (k >= 0) h = hot[k];
+        actions[(size_t)tree * Kmax + a] = k >= 0 ? P.action[tb + k] : 0.0f;
+        counts[(size_t)tree * Kmax + a] = k >= 0 ? h.edge_n : 0;
+        Q[(size_t)tree * Kmax + a] = k >= 0 ? h.Q : 0.0;
+        bool ex = k >= 0 && (h.flags & FLAG_EXPANDED);
+        child_n[(size_t)tree * Kmax + a] = ex ? h.node_n : -1;
+        for (int s = 0; s < P.S; ++s) child_state[((size_t)tree * Kmax + a) * P.S + s] = ex ? P.state[(tb + k) * P.S + s] : 0.0;
+        if (k >= 0) {
+            if (a == 0 || h.Q > qmax) qmax = h.Q;
+            if (P.mode == AZG_MODE_DISCRETE) onp += ((double)h.edge_n / (double)tot) * h.Q;
+        }
+    }
+    if (P.mode == AZG_MODE_CONTINUOUS) {
+        // reference quirk (mcts.py:111 with Q of shape (K,1)): the K x K outer product is summed
+        for (int a = 0; a < nc; ++a)
+            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+    }
+    vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
+    nch[tree] = nc;
+    root_V[tree] = P.node_V[tb];
+    for (int d = 0; d < P.nd; ++d) root_dist[(size_t)tree * P.nd + d] = P.dist[tb * P.nd + d];
+}
+
+__global__ void math_selftest_kernel(int fn_id, const double* in, double* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = in[i], s, c;
+    switch (fn_id) {
+        case 0: out[i] = (double)azg_expf((float)x); break;
+        case 1: out[i] = (double)azg_expm1f((float)x); break;
+        case 2: out[i] = (double)azg_tanhf((float)x); break;
+        case 3: out[i] = (double)azg_logf((float)x); break;
+        case 4: out[i] = (double)azg_cos2pif((float)x); break;
+        case 5: azg_sincos(x, &s, &c); out[i] = s; break;
+        case 6: azg_sincos(x, &s, &c); out[i] = c; break;
+        case 7: out[i] = azg_pymod(x, 2.0 * 3.141592653589793); break;
+        case 8: out[i] = (double)azg_normal(34u, (uint32_t)x, 0u, (uint32_t)(x * 7.0)); break;
+        case 9: out[i] = (double)((float)x / 3.0f); break;
+        case 10: out[i] = (double)__builtin_sqrtf((float)x); break;
+        case 11: out[i] = x / 3.0; break;
+        default: out[i] = 0.0;
+    }
+}
+
+// fn_id 100: one 16x16x4 MFMA chain over n/… ; in = [a0..a(K-1), b0..b(K-1), c], out[0] = D[0][0]; probes the accumulation order
+__global__ void mfma_probe_kernel(const double* in, double* out, int K) {
+    int lane = threadIdx.x;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float c = (float)in[2 * K];
+    acc.x = acc.y = acc.z = acc.w = c;
+    for (int s = 0; s < K / 4; ++s) {
+        int k = 4 * s + (lane >> 4);
+        float a = (float)in[k];
+        float b = (float)in[K + k];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    if (lane == 0) out[0] = (double)acc.x;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+struct azg_engine {
+    azg_config cfg;
+    int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
+    int mlp_ready, HP, n_hidden, n_out, act, nreg;
+    float ls_min, ls_max;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    KParams P;
+    std::vector<void*> dev_allocs;
+    std::vector<void*> weight_allocs;
+    // results staging
+    float* d_actions; int* d_counts; double* d_Q; double* d_vt; int* d_nch; int* d_child_n; double* d_child_state;
+    float* d_rootV; float* d_rootdist;
+    double* d_roots; int* d_carry;
+    uint32_t search_idx;
+    int searched, results_valid;
+    float last_ms;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int fail(azg_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _rc = (call);                                                                         \
+        if (_rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(_rc)); \
+    } while (0)
+
+template <typename T>
+static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
+    void* q = nullptr;
+    hipError_t rc = hipMalloc(&q, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
+    if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(rc));
+    reg.push_back(q);
+    *p = (T*)q;
+    return AZG_OK;
+}
+
+template <int ENV, int HP, int NREG>
+static hipError_t launch(azg_engine* e, size_t dyn) {
+    dim3 grid((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG), block(256);
+    hipLaunchKernelGGL((search_kernel<ENV, HP, NREG>), grid, block, dyn, e->stream, e->P);
+    return hipGetLastError();
+}
+
+template <int ENV>
+static hipError_t dispatch(azg_engine* e, size_t dyn) {
+    const int HP = e->HP, NR = e->nreg;
+    if (HP == 64) {
+        if (NR == 1) return launch<ENV, 64, 1>(e, dyn);
+        if (NR == 2) return launch<ENV, 64, 2>(e, dyn);
+        if (NR == 3) return launch<ENV, 64, 3>(e, dyn);
+        return launch<ENV, 64, 0>(e, dyn);
+    }
+    if (HP == 128) {
+        if (NR == 1) return launch<ENV, 128, 1>(e, dyn);
+        if (NR == 2) return launch<ENV, 128, 2>(e, dyn);
+        if (NR == 3) return launch<ENV, 128, 3>(e, dyn);
+        return launch<ENV, 128, 0>(e, dyn);
+    }
+    if (HP == 256) {
+        if (NR == 1) return launch<ENV, 256, 1>(e, dyn);
+        return launch<ENV, 256, 0>(e, dyn);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" {
+
+int azg_abi_version(void) { return AZG_ABI_VERSION; }
+
+const char* azg_last_error(const azg_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+void azg_engine_destroy(azg_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device_id);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->dev_allocs) (void)hipFree(p);
+    for (void* p : e->weight_allocs) (void)hipFree(p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int azg_engine_create(const azg_config* cfg, azg_engine** out) {
+    if (!cfg || !out) return fail(nullptr, AZG_E_INVALID, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
+    if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
+    if (cfg->env_id < 0 || cfg->env_id > 2) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
+    if (cfg->mode == AZG_MODE_DISCRETE && cfg->env_id != AZG_ENV_CARTPOLE)
+        return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole)");
+    if (cfg->mode == AZG_MODE_CONTINUOUS && cfg->env_id == AZG_ENV_CARTPOLE)
+        return fail(nullptr, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
+    if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != 2) return fail(nullptr, AZG_E_INVALID, "CartPole has num_actions == 2");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_E_DEVICE, "no HIP device available");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, AZG_E_DEVICE, "device_id out of range");
+    azg_engine* e = new azg_engine();
+    e->cfg = *cfg;
+    e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
+    e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f;
+    e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
+    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 3;
+    const int ns = cfg->n_sims;
+    std::vector<int> pw(ns + 2, 0);
+    if (cfg->mode == AZG_MODE_CONTINUOUS) {
+        int kmax = 1;
+        for (int n = 0; n < ns + 2; ++n) {
+            // NodeContinuous.check_pw (states.py:271-273): python float pow + math.ceil, evaluated on the host with libm
+            double v = std::ceil(cfg->c_pw * std::pow((double)(n + 1), cfg->kappa));
+            if (v > 1e6) v = 1e6;
+            pw[n] = (int)v;
+            if (n < ns && pw[n] > kmax) kmax = pw[n];
+        }
+        e->Kmax = kmax;
+        e->R = ns + 2;
+        e->nd = 2;
+    } else {
+        e->Kmax = cfg->num_actions;
+        e->R = 1 + cfg->num_actions * (ns + 1);
+        e->nd = cfg->num_actions;
+    }
+    if (e->R > 32767) { delete e; return fail(nullptr, AZG_E_UNSUPPORTED, "tree too large: records per tree must be < 32768"); }
+    e->Kp = (e->Kmax + 15) / 16 * 16;
+    e->tab_n = 4 * ns + 4;
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
+#define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
+#define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
+    HK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HK(hipEventCreate(&e->ev0));
+    HK(hipEventCreate(&e->ev1));
+    KParams& P = e->P;
+    memset(&P, 0, sizeof(P));
+    const size_t B = (size_t)cfg->n_trees, R = (size_t)e->R;
+    Hot* hot; double* node_r; float* node_V; float* action; float* dist; double* state; unsigned short* child; int* n_rec;
+    int* d_pw; double* d_sq;
+    CK(dalloc(e, &hot, B * R, e->dev_allocs));
+    CK(dalloc(e, &node_r, B * R, e->dev_allocs));
+    CK(dalloc(e, &node_V, B * R, e->dev_allocs));
+    CK(dalloc(e, &action, B * R, e->dev_allocs));
+    CK(dalloc(e, &dist, B * R * e->nd, e->dev_allocs));
+    CK(dalloc(e, &state, B * R * e->S_env, e->dev_allocs));
+    CK(dalloc(e, &child, B * R * e->Kp, e->dev_allocs));
+    CK(dalloc(e, &n_rec, B, e->dev_allocs));
+    CK(dalloc(e, &d_pw, (size_t)ns + 2, e->dev_allocs));
+    CK(dalloc(e, &d_sq, (size_t)e->tab_n, e->dev_allocs));
+    CK(dalloc(e, &e->d_roots, B * e->S_env, e->dev_allocs));
+    CK(dalloc(e, &e->d_carry, B, e->dev_allocs));
+    const size_t K = (size_t)e->Kmax;
+    CK(dalloc(e, &e->d_actions, B * K, e->dev_allocs));
+    CK(dalloc(e, &e->d_counts, B * K, e->dev_allocs));
+    CK(dalloc(e, &e->d_Q, B * K, e->dev_allocs));
+    CK(dalloc(e, &e->d_vt, B, e->dev_allocs));
+    CK(dalloc(e, &e->d_nch, B, e->dev_allocs));
+    CK(dalloc(e, &e->d_child_n, B * K, e->dev_allocs));
+    CK(dalloc(e, &e->d_child_state, B * K * e->S_env, e->dev_allocs));
+    CK(dalloc(e, &e->d_rootV, B, e->dev_allocs));
+    CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
+    std::vector<double> sq(e->tab_n);
+    for (int n = 0; n < e->tab_n; ++n) sq[n] = std::sqrt((double)(n + 1));
+    HK(hipMemcpy(d_pw, pw.data(), sizeof(int) * (ns + 2), hipMemcpyHostToDevice));
+    HK(hipMemcpy(d_sq, sq.data(), sizeof(double) * e->tab_n, hipMemcpyHostToDevice));
+    HK(hipMemset(hot, 0, B * R * sizeof(Hot)));
+    HK(hipMemset(e->d_carry, 0, B * sizeof(int)));
+    P.B = cfg->n_trees; P.n_sims = ns; P.R = e->R; P.Kp = e->Kp; P.A = cfg->num_actions; P.nd = e->nd;
+    P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
+    P.c_uct = cfg->c_uct; P.gamma = cfg->gamma; P.epsilon = cfg->epsilon; P.reward_scale = cfg->reward_scale;
+    P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;
+    P.seed = cfg->seed; P.S = e->S_env; P.tab_n = e->tab_n;
+    P.roots = e->d_roots; P.carry = e->d_carry;
+    P.hot = hot; P.node_r = node_r; P.node_V = node_V; P.action = action; P.dist = dist; P.state = state; P.child = child;
+    P.n_rec = n_rec; P.pw_need = d_pw; P.sqrt_tab = d_sq;
+    *out = e;
+    return AZG_OK;
+#undef CK
+#undef HK
+}
+
+static int pad64(int n) { return (n + 63) / 64 * 64; }
+static inline int unit_of(int i) { int t = i >> 4, r = (i >> 2) & 3, g = i & 3; return 16 * t + 4 * g + r; }
+
+int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, size_t n_floats) {
+    if (!e || !d || !blob) return AZG_E_INVALID;
+    if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
+    if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
+    if (d->in_dim != e->S_obs) return fail(e, AZG_E_INVALID, "in_dim does not match the env observation");
+    if (d->n_dist != e->nd) return fail(e, AZG_E_INVALID, "n_dist does not match the engine mode");
+    if (1 + d->n_dist > 16) return fail(e, AZG_E_UNSUPPORTED, "at most 15 distribution outputs");
+    size_t need = 0;
+    int k = d->in_dim, hmax = 0;
+    for (int l = 0; l < d->n_hidden; ++l) {
+        if (d->hidden[l] < 1 || d->hidden[l] > 4096) return fail(e, AZG_E_INVALID, "hidden width out of range");
+        need += (size_t)d->hidden[l] * k + d->hidden[l];
+        k = d->hidden[l];
+        if (k > hmax) hmax = k;
+    }
+    need += (size_t)(1 + d->n_dist) * k + (1 + d->n_dist);
+    if (need != n_floats) return fail(e, AZG_E_INVALID, "weight blob size mismatch");
+    const int HP = pad64(hmax);
+    if (HP != 64 && HP != 128 && HP != 256)
+        return fail(e, AZG_E_UNSUPPORTED, "hidden width (padded to a multiple of 64) must be one of 64,128,256");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (void* p : e->weight_allocs) (void)hipFree(p);
+    e->weight_allocs.clear();
+    const int NT = HP / 16, S4 = HP / 16;
+    // unpack the torch-layout blob into zero-padded [HP][Kp] matrices
+    std::vector<std::vector<float>> Wd(d->n_hidden), bd(d->n_hidden);
+    const float* p = blob;
+    int kt = d->in_dim, kp = 4;
+    for (int l = 0; l < d->n_hidden; ++l) {
+        int h = d->hidden[l];
+        Wd[l].assign((size_t)HP * kp, 0.0f);
+        bd[l].assign(HP, 0.0f);
+        for (int n = 0; n < h; ++n)
+            for (int kk = 0; kk < kt; ++kk) Wd[l][(size_t)n * kp + kk] = p[(size_t)n * kt + kk];
+        p += (size_t)h * kt;
+        for (int n = 0; n < h; ++n) bd[l][n] = p[n];
+        p += h;
+        kt = h; kp = HP;
+    }
+    const int n_out = 1 + d->n_dist;
+    std::vector<float> Wh((size_t)16 * HP, 0.0f), bh(16, 0.0f);
+    for (int kk = 0; kk < kt; ++kk) Wh[kk] = p[kk];
+    p += kt;
+    bh[0] = *p++;
+    for (int o = 0; o < d->n_dist; ++o)
+        for (int kk = 0; kk < kt; ++kk) Wh[(size_t)(1 + o) * HP + kk] = p[(size_t)o * kt + kk];
+    p += (size_t)d->n_dist * kt;
+    for (int o = 0; o < d->n_dist; ++o) bh[1 + o] = p[o];
+    // MFMA operand layouts (lane l: row/col = l & 15, k-slot g = l >> 4; D register r of tile t = unit 16t + 4g + r)
+    std::vector<float> W0s((size_t)NT * 64), b0s((size_t)NT * 64 * 4);
+    for (int t = 0; t < NT; ++t)
+        for (int l = 0; l < 64; ++l) {
+            int row = 16 * t + (l & 15), g = l >> 4;
+            W0s[(size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
+            for (int r = 0; r < 4; ++r) b0s[((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
+        }
+    float *dW0, *db0, *dWh, *dbh;
+    if (dalloc(e, &dW0, W0s.size(), e->weight_allocs)) return AZG_E_DEVICE;
+    if (dalloc(e, &db0, b0s.size(), e->weight_allocs)) return AZG_E_DEVICE;
+    HIPCHK(e, hipMemcpy(dW0, W0s.data(), W0s.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(db0, b0s.data(), b0s.size() * 4, hipMemcpyHostToDevice));
+    e->P.W0 = dW0;
+    e->P.b0 = (const f32x4*)db0;
+    for (int l = 1; l < d->n_hidden; ++l) {
+        std::vector<float> Ws((size_t)NT * S4 * 64 * 4), bs((size_t)NT * 64 * 4);
+        for (int t = 0; t < NT; ++t)
+            for (int l64 = 0; l64 < 64; ++l64) {
+                int row = 16 * t + (l64 & 15), g = l64 >> 4;
+                for (int s4 = 0; s4 < S4; ++s4)
+                    for (int j = 0; j < 4; ++j) {
+                        int i = 4 * (4 * s4 + j) + g;   // canonical position consumed by k-slot g of step 4*s4+j
+                        Ws[(((size_t)t * S4 + s4) * 64 + l64) * 4 + j] = Wd[l][(size_t)row * HP + unit_of(i)];
+                    }
+                for (int r = 0; r < 4; ++r) bs[((size_t)t * 64 + l64) * 4 + r] = bd[l][16 * t + 4 * g + r];
+            }
+        float *dW, *db;
+        if (dalloc(e, &dW, Ws.size(), e->weight_allocs)) return AZG_E_DEVICE;
+        if (dalloc(e, &db, bs.size(), e->weight_allocs)) return AZG_E_DEVICE;
+        HIPCHK(e, hipMemcpy(dW, Ws.data(), Ws.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(db, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+        e->P.Wl[l - 1] = (const f32x4*)dW;
+        e->P.bl[l - 1] = (const f32x4*)db;
+    }
+    std::vector<float> Whs((size_t)S4 * 64 * 4);
+    for (int s4 = 0; s4 < S4; ++s4)
+        for (int l64 = 0; l64 < 64; ++l64) {
+            int o = l64 & 15, g = l64 >> 4;
+            for (int j = 0; j < 4; ++j) {
+                int i = 4 * (4 * s4 + j) + g;
+                Whs[((size_t)s4 * 64 + l64) * 4 + j] = Wh[(size_t)o * HP + unit_of(i)];
+            }
+        }
+    if (dalloc(e, &dWh, Whs.size(), e->weight_allocs)) return AZG_E_DEVICE;
+    if (dalloc(e, &dbh, (size_t)16, e->weight_allocs)) return AZG_E_DEVICE;
+    HIPCHK(e, hipMemcpy(dWh, Whs.data(), Whs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(dbh, bh.data(), 16 * 4, hipMemcpyHostToDevice));
+    e->P.Whead = (const f32x4*)dWh;
+    e->P.bhead = dbh;
+    e->HP = HP; e->n_hidden = d->n_hidden; e->n_out = n_out; e->act = d->activation;
+    e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
+    // hidden->hidden layers that fit the register file stay there for the whole search
+    int nhh = d->n_hidden - 1;
+    int regs = nhh * (HP * HP / 64);
+    e->nreg = (nhh >= 1 && nhh <= 3 && regs <= 288) ? nhh : 0;
+    const char* force = getenv("AZG_FORCE_STREAM_WEIGHTS");
+    if (force && force[0] == '1') e->nreg = 0;
+    e->mlp_ready = 1;
+    return AZG_OK;
+}
+
+int azg_set_search_index(azg_engine* e, uint32_t idx) { if (!e) return AZG_E_INVALID; e->search_idx = idx; return AZG_OK; }
+
+int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
+    if (!e || !roots) return AZG_E_INVALID;
+    const int B = e->cfg.n_trees, S = e->S_env;
+    if (e->cfg.env_id == AZG_ENV_CARTPOLE) {
+        const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
+        for (int i = 0; i < B; ++i) {
+            const double* s = roots + (size_t)i * S;
+            if ((s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr))
+                return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
+        }
+    }
+    if (carry)
+        for (int i = 0; i < B; ++i)
+            if (carry[i] < 0 || carry[i] > 3 * e->cfg.n_sims) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipMemcpyAsync(e->d_roots, roots, sizeof(double) * (size_t)B * S, hipMemcpyHostToDevice, e->stream));
+    if (carry) HIPCHK(e, hipMemcpyAsync(e->d_carry, carry, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(e, hipMemsetAsync(e->d_carry, 0, sizeof(int) * (size_t)B, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return AZG_OK;
+}
+
+int azg_search_resident(azg_engine* e) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    e->P.search_idx = e->search_idx;
+    size_t dyn = sizeof(double) * (size_t)e->tab_n + sizeof(int) * (size_t)(e->cfg.n_sims + 2);
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    hipError_t rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e, dyn) : dispatch<AZG_ENV_PENDULUM_V1>(e, dyn);
+    if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    e->search_idx += 1;
+    e->searched = 1;
+    e->results_valid = 0;
+    return AZG_OK;
+}
+
+int azg_sync(azg_engine* e) {
+    if (!e) return AZG_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return AZG_OK;
+}
+
+int azg_search(azg_engine* e, const double* roots, const int32_t* carry) {
+    int rc = azg_upload_roots(e, roots, carry);
+    if (rc) return rc;
+    rc = azg_search_resident(e);
+    if (rc) return rc;
+    return azg_sync(e);
+}
+
+int azg_last_search_ms(azg_engine* e, float* ms) {
+    if (!e || !ms) return AZG_E_INVALID;
+    if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipEventSynchronize(e->ev1));
+    HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return AZG_OK;
+}
+
+static int gather_results(azg_engine* e) {
+    if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
+    if (e->results_valid) return AZG_OK;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    int B = e->cfg.n_trees;
+    hipLaunchKernelGGL(results_kernel, dim3((B + 127) / 128), dim3(128), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
+                       e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->results_valid = 1;
+    return AZG_OK;
+}
+
+#define D2H(dst, src, bytes) do { if (dst) HIPCHK(e, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); } while (0)
+
+int azg_results(azg_engine* e, float* actions, int32_t* counts, double* Q, double* v_target, int32_t* n_children) {
+    if (!e) return AZG_E_INVALID;
+    int rc = gather_results(e);
+    if (rc) return rc;
+    size_t B = e->cfg.n_trees, K = e->Kmax;
+    D2H(actions, e->d_actions, B * K * 4);
+    D2H(counts, e->d_counts, B * K * 4);
+    D2H(Q, e->d_Q, B * K * 8);
+    D2H(v_target, e->d_vt, B * 8);
+    D2H(n_children, e->d_nch, B * 4);
+    return AZG_OK;
+}
+
+int azg_root_children(azg_engine* e, int32_t* child_n, double* child_state) {
+    if (!e) return AZG_E_INVALID;
+    int rc = gather_results(e);
+    if (rc) return rc;
+    size_t B = e->cfg.n_trees, K = e->Kmax;
+    D2H(child_n, e->d_child_n, B * K * 4);
+    D2H(child_state, e->d_child_state, B * K * e->S_env * 8);
+    return AZG_OK;
+}
+
+int azg_root_eval(azg_engine* e, float* value, float* dist) {
+    if (!e) return AZG_E_INVALID;
+    int rc = gather_results(e);
+    if (rc) return rc;
+    size_t B = e->cfg.n_trees;
+    D2H(value, e->d_rootV, B * 4);
+    D2H(dist, e->d_rootdist, B * e->nd * 4);
+    return AZG_OK;
+}
+
+int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* edge_n, double* edge_W, double* edge_Q,
+                  float* edge_action, int32_t* node_n, double* node_r, float* node_V, uint8_t* node_flags) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    size_t B = e->cfg.n_trees, R = e->R;
+    std::vector<Hot> hot(B * R);
+    std::vector<int> nrec(B);
+    std::vector<double> nr(B * R);
+    std::vector<float> nv(B * R), ac(B * R);
+    HIPCHK(e, hipMemcpy(hot.data(), e->P.hot, B * R * sizeof(Hot), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(nrec.data(), e->P.n_rec, B * 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(nr.data(), e->P.node_r, B * R * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(nv.data(), e->P.node_V, B * R * 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(ac.data(), e->P.action, B * R * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < B; ++i) {
+        if (n_records) n_records[i] = nrec[i];
+        for (size_t j = 0; j < R; ++j) {
+            size_t o = i * R + j;
+            bool in = (int)j < nrec[i];
+            const Hot& h = hot[o];
+            bool ex = in && (h.flags & FLAG_EXPANDED);
+            if (parent) parent[o] = in ? h.parent : 0;
+            if (edge_n) edge_n[o] = in ? h.edge_n : 0;
+            if (edge_W) edge_W[o] = in ? h.W : 0.0;
+            if (edge_Q) edge_Q[o] = in ? h.Q : 0.0;
+            if (edge_action) edge_action[o] = in ? ac[o] : 0.0f;
+            if (node_n) node_n[o] = in ? h.node_n : 0;
+            if (node_r) node_r[o] = ex ? nr[o] : 0.0;
+            if (node_V) node_V[o] = ex ? nv[o] : 0.0f;
+            if (node_flags) node_flags[o] = in ? h.flags : 0;
+        }
+    }
+    return AZG_OK;
+}
+
+int azg_max_children(const azg_engine* e) { return e ? e->Kmax : AZG_E_INVALID; }
+int azg_max_records(const azg_engine* e) { return e ? e->R : AZG_E_INVALID; }
+int azg_env_state_dim(const azg_engine* e) { return e ? e->S_env : AZG_E_INVALID; }
+int azg_obs_dim(const azg_engine* e) { return e ? e->S_obs : AZG_E_INVALID; }
+
+int azg_synthetic_roots(azg_engine* e, double* roots) {
+    if (!e || !roots) return AZG_E_INVALID;
+    const double pi = 3.141592653589793;
+    for (int i = 0; i < e->cfg.n_trees; ++i) {
+        azg_u32x4 b = azg_draw(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, 0u, AZG_STREAM_ROOT);
+        double u[4];
+        for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
+        double* r = roots + (size_t)i * e->S_env;
+        if (e->cfg.env_id == AZG_ENV_CARTPOLE) for (int k = 0; k < 4; ++k) r[k] = -0.05 + 0.1 * u[k];
+        else { r[0] = -pi + 2.0 * pi * u[0]; r[1] = -1.0 + 2.0 * u[1]; }
+    }
+    return AZG_OK;
+}
+
+int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, size_t n) {
+    if (!in || !out || n == 0) return AZG_E_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return AZG_E_DEVICE;
+    double *di = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&di, n * 8) != hipSuccess) return AZG_E_DEVICE;
+    if (hipMalloc((void**)&dout, n * 8) != hipSuccess) { (void)hipFree(di); return AZG_E_DEVICE; }
+    int rc = AZG_OK;
+    if (hipMemcpy(di, in, n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = AZG_E_DEVICE;
+    if (rc == AZG_OK) {
+        if (fn_id == 100) {
+            int K = (int)((n - 1) / 2);
+            hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, di, dout, K);
+        } else {
+            hipLaunchKernelGGL(math_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn_id, di, dout, n);
+        }
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = AZG_E_DEVICE;
+    }
+    if (rc == AZG_OK && hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AZG_E_DEVICE;
+    (void)hipFree(di);
+    (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

@@ -40,7 +40,7 @@
 
 typedef struct {
     int n_layers;              /* hidden layers */
-    int in_dim;
+    int in_dim, in_pad;
     int hid[AZG_MAX_HIDDEN_LAYERS];   /* true widths */
     int hidp[AZG_MAX_HIDDEN_LAYERS];  /* padded to a multiple of 64 */
     int n_out;                 /* 1 + n_dist */
@@ -182,8 +182,8 @@ static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
     float bufa[4096], bufb[4096];
     float* x = bufa;
     float* h = bufb;
-    int kp = m->in_dim;
-    for (int i = 0; i < kp; ++i) x[i] = obs[i];
+    int kp = m->in_pad;
+    for (int i = 0; i < kp; ++i) x[i] = i < m->in_dim ? obs[i] : 0.0f;
     for (int l = 0; l < m->n_layers; ++l) {
         int hp = m->hidp[l];
         for (int n = 0; n < hp; ++n) {
@@ -324,9 +324,14 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     m->n_layers = d->n_hidden; m->in_dim = d->in_dim; m->n_out = 1 + d->n_dist; m->act = d->activation;
     m->ls_min = d->log_std_min; m->ls_max = d->log_std_max;
     const float* p = blob;
-    int kt = d->in_dim, kp = d->in_dim;
+    /* every hidden layer is zero-padded to one common width HP (multiple of 64); the input to 4 slots */
+    int hmax = 0;
+    for (int l = 0; l < d->n_hidden; ++l) if (d->hidden[l] > hmax) hmax = d->hidden[l];
+    const int HP = pad64(hmax);
+    int kt = d->in_dim, kp = (d->in_dim + 3) / 4 * 4;
+    m->in_pad = kp;
     for (int l = 0; l < d->n_hidden; ++l) {
-        int h = d->hidden[l], hp = pad64(h);
+        int h = d->hidden[l], hp = HP;
         m->hid[l] = h; m->hidp[l] = hp;
         m->W[l] = (float*)calloc((size_t)hp * kp, 4);
         m->b[l] = (float*)calloc(hp, 4);

@@ -1,0 +1,167 @@
+"""GPU (-m gpu): the HIP engine against the CPU oracle and the reference's golden vectors, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as P
+from alphazero_gym_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from alphazero_gym_amd import _native
+    _native.lib()
+    return _native
+
+
+MATH_INPUTS = {
+    0: np.linspace(-90, 10, 20001), 1: np.linspace(-20, 3, 20001), 2: np.linspace(-12, 12, 20001),
+    3: np.linspace(1e-8, 1.0, 20001), 4: np.linspace(0, 0.99999, 20001), 5: np.linspace(-100, 100, 20001),
+    6: np.linspace(-100, 100, 20001), 7: np.linspace(-100, 100, 20001), 8: np.arange(20001, dtype=np.float64),
+    9: np.linspace(-50, 50, 20001), 10: np.linspace(0, 50, 20001), 11: np.linspace(-50, 50, 20001),
+}
+
+
+@pytest.mark.parametrize("fn_id", sorted(MATH_INPUTS))
+def test_device_math_is_bit_identical_to_host(native, fn_id):
+    x = MATH_INPUTS[fn_id]
+    host = O.math_eval(fn_id, x)
+    dev = native.math_selftest(fn_id, x)
+    np.testing.assert_array_equal(host.view(np.uint64), dev.view(np.uint64))
+
+
+def test_mfma_f32_is_a_k_ordered_fma_chain(native):
+    """v_mfma_f32_16x16x4_f32 must accumulate D = fma(a_k, b_k, D) for k = 0, 1, 2, ... (the oracle's MLP order)."""
+    rng = np.random.Generator(np.random.PCG64(1))
+    K = 64
+    a = rng.standard_normal(K).astype(np.float32)
+    b = (rng.standard_normal(K) * 10 ** rng.uniform(-3, 3, K)).astype(np.float32)
+    c = np.float32(0.3)
+    dev = native.math_selftest(100, np.concatenate([a, b, [c]]).astype(np.float64))[0]
+    acc = np.float64(c)
+    chain = np.float32(c)
+    for k in range(K):
+        # float32 fma: exact product in float64 (24+24 bits), one rounding after the add (double rounding is vanishingly rare)
+        chain = np.float32(np.float64(a[k]) * np.float64(b[k]) + np.float64(chain))
+    assert np.float32(dev) == chain, (dev, chain, acc)
+
+
+def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0):
+    e = engine_cls(**kw)
+    e.set_weights(desc, blob)
+    e.set_search_index(sidx)
+    e.search(roots, carry)
+    out = (e.results(), e.dump_tree(), e.root_children(), e.root_eval())
+    e.close()
+    return out
+
+
+def _assert_same(a, b):
+    for da, db in zip(a, b):
+        if isinstance(da, dict):
+            for k in da:
+                np.testing.assert_array_equal(da[k], db[k], err_msg=k)
+        else:
+            for x, y in zip(da, db):
+                np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("name", P.T1_NAMES)
+def test_hip_matches_reference_goldens(native, name):
+    case, z = P.load_case(name)
+    out = P.run_case(native.HipEngine, case, z)
+    P.compare_rows(out, z, float_tol=1e-12)
+    # and bit for bit against the oracle on the same inputs
+    ref = P.run_case(O.OracleEngine, case, z)
+    for (r1, d1, c1), (r2, d2, c2) in zip(out, ref):
+        for k in r1:
+            np.testing.assert_array_equal(r1[k], r2[k], err_msg=k)
+        for k in d1:
+            np.testing.assert_array_equal(d1[k], d2[k], err_msg=k)
+        np.testing.assert_array_equal(c1, c2)
+
+
+CONFIGS = [
+    # (env, mode, hidden, act, n_sims, extra)
+    (2, 1, [256, 256], "elu", 200, dict(c_uct=0.05, gamma=1.0)),
+    (2, 1, [256, 256], "elu", 64, dict(c_uct=0.3, gamma=0.97, c_pw=2.5, kappa=0.7, epsilon=0.2, v_target="on_policy")),
+    (1, 1, [128, 128, 128], "elu", 90, dict(c_uct=0.1, gamma=0.99, c_pw=1.0, kappa=0.5)),
+    (2, 1, [64], "relu", 50, dict(c_uct=0.05, gamma=1.0, c_pw=3.0, kappa=0.9)),
+    (2, 1, [100, 60], "elu", 40, dict(c_uct=0.05, gamma=1.0)),
+    (2, 1, [128, 128, 128, 128, 128], "relu", 30, dict(c_uct=0.05, gamma=1.0)),
+    (0, 0, [128, 128], "relu", 100, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
+    (0, 0, [64, 64], "elu", 60, dict(c_uct=20.0, gamma=0.95, epsilon=0.1, num_actions=2, v_target="on_policy")),
+    (0, 0, [256, 256], "relu", 80, dict(c_uct=5.0, gamma=0.99, num_actions=2)),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
+@pytest.mark.parametrize("stream", [0, 1])
+def test_hip_bit_exact_vs_oracle(native, cfg, stream, monkeypatch):
+    """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical."""
+    env, mode, hidden, act, n_sims, extra = cfg
+    if stream:
+        monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
+    B = 37
+    kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
+    in_dim, n_dist = (3, 2) if mode == 1 else (4, 2)
+    desc = _capi.make_desc(in_dim, hidden, n_dist, act)
+    blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
+    o = O.OracleEngine(**kw)
+    roots = o.synthetic_roots()
+    o.close()
+    if mode == 0:
+        roots[3] = [2.35, 1.5, 0.0, 0.0]      # terminates quickly
+        roots[5] = [0.0, 0.0, 0.2, 1.0]
+    carry = (np.arange(B) % 7).astype(np.int32) if mode == 0 else None
+    a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3)
+    b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=3)
+    _assert_same(a, b)
+
+
+def test_terminal_root_raises(native):
+    e = native.HipEngine(env_id=0, mode=0, n_trees=2, n_sims=4, c_uct=1.5, gamma=1.0, num_actions=2)
+    e.set_weights(_capi.make_desc(4, [64], 2, "relu"), O.make_weights(1, 4, [64], 2))
+    with pytest.raises(ValueError):
+        e.search(np.array([[0.0, 0, 0, 0], [3.0, 0, 0, 0]]))
+    e.close()
+
+
+def test_full_size_properties(native):
+    """BASELINE config C (Pendulum-v1, 4096 trees, n_sims 200, 2x256 elu): size-independent invariants
+    + a seeded subset bit-exact against the oracle."""
+    B, NS = 4096, 200
+    kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+    desc = _capi.make_desc(3, [256, 256], 2, "elu")
+    blob = O.make_weights(34, 3, [256, 256], 2)
+    e = native.HipEngine(**kw)
+    e.set_weights(desc, blob)
+    roots = e.synthetic_roots()
+    e.search(roots)
+    r, d = e.results(), e.dump_tree()
+    assert (r["counts"].sum(1) == NS).all()                       # sum of root counts == n_sims
+    assert (r["n_children"] == 15).all()                          # ceil(sqrt(200)) children at the root
+    assert (d["n_records"] == NS + 1).all()                       # one new node per trace
+    assert (d["node_n"][:, 0] == NS).all()
+    # node.n == sum of child edge counts, for every node of every tree
+    for t in range(0, B, 257):
+        par, en, nn = d["parent"][t], d["edge_n"][t], d["node_n"][t]
+        acc = np.zeros_like(nn)
+        np.add.at(acc, par[1:NS + 1], en[1:NS + 1])
+        np.testing.assert_array_equal(acc[:NS + 1], nn[:NS + 1])
+    sel = np.arange(0, B, 128)
+    o = O.OracleEngine(**dict(kw, n_trees=len(sel)))
+    o.set_weights(desc, blob)
+    # same global tree ids -> same noise: run the subset one engine per tree id
+    for i, t in enumerate(sel):
+        oo = O.OracleEngine(**dict(kw, n_trees=1, tree_id_base=int(t)))
+        oo.set_weights(desc, blob)
+        oo.search(roots[t:t + 1])
+        ro, do = oo.results(), oo.dump_tree()
+        np.testing.assert_array_equal(ro["counts"][0], r["counts"][t])
+        np.testing.assert_array_equal(ro["Q"][0], r["Q"][t])
+        np.testing.assert_array_equal(do["edge_W"][0], d["edge_W"][t])
+        oo.close()
+    e.close()
