@@ -6,7 +6,8 @@ import os
 from . import _capi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libazgym_hip.so")
+# AZG_HIP_LIB: diagnostic builds only (e.g. the -DAZG_STAMPS library used by tools/phase_profile.py)
+LIB_PATH = os.environ.get("AZG_HIP_LIB") or os.path.join(HERE, "csrc", "libazgym_hip.so")
 
 _lib = None
 _fns = None

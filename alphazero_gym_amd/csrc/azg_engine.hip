@@ -71,7 +71,16 @@ struct KParams {
     const f32x4* bl[MAX_STREAM_LAYERS]; // [HP/16][64]
     const f32x4* Whead;      // [HP/16 s4][64]
     const float* bhead;      // [16]
+    unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };
+
+#ifdef AZG_STAMPS
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t0, t1)
+#endif
 
 // ------------------------------------------------------------------------------------------------ environments
 
@@ -136,15 +145,49 @@ __device__ __forceinline__ void pendulum_step(int v1, const double* s, float act
 
 // ------------------------------------------------------------------------------------------------ MLP on MFMA
 
-__device__ __forceinline__ float act_fn(int act, float x) {
-    if (act == AZG_ACT_ELU) return x > 0.0f ? x : azg_expm1f(x);
-    return x > 0.0f ? x : 0.0f;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// azg_expm1f on four values at once: the same operations in the same order per component (bit-identical), written
+// component-parallel so that the four dependent fma chains interleave (and pack into v_pk_fma_f32)
+__device__ __forceinline__ f32x4 expm1f4(f32x4 x) {
+    const f32x4 lo = {-87.0f, -87.0f, -87.0f, -87.0f}, hi = {88.0f, 88.0f, 88.0f, 88.0f};
+    i32x4 mlo = x < lo, mhi = x > hi;
+    f32x4 xc = (f32x4)((((i32x4)lo) & mlo) | ((((i32x4)hi) & mhi) | (((i32x4)x) & ~(mlo | mhi))));
+    const f32x4 magic = {12582912.0f, 12582912.0f, 12582912.0f, 12582912.0f};
+    const f32x4 l2e = {1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f};
+    const f32x4 ln2h = {0.693145751953125f, 0.693145751953125f, 0.693145751953125f, 0.693145751953125f};
+    const f32x4 ln2l = {1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f};
+    f32x4 kf = __builtin_elementwise_fma(xc, l2e, magic);
+    kf = kf - magic;
+    f32x4 r = __builtin_elementwise_fma(-kf, ln2h, xc);
+    r = __builtin_elementwise_fma(-kf, ln2l, r);
+    f32x4 p = {1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f};
+    const f32x4 c5 = {1.38888888888888894e-3f, 1.38888888888888894e-3f, 1.38888888888888894e-3f, 1.38888888888888894e-3f};
+    const f32x4 c4 = {8.33333333333333322e-3f, 8.33333333333333322e-3f, 8.33333333333333322e-3f, 8.33333333333333322e-3f};
+    const f32x4 c3 = {4.16666666666666644e-2f, 4.16666666666666644e-2f, 4.16666666666666644e-2f, 4.16666666666666644e-2f};
+    const f32x4 c2 = {1.66666666666666657e-1f, 1.66666666666666657e-1f, 1.66666666666666657e-1f, 1.66666666666666657e-1f};
+    const f32x4 half = {0.5f, 0.5f, 0.5f, 0.5f}, one = {1.0f, 1.0f, 1.0f, 1.0f};
+    p = __builtin_elementwise_fma(p, r, c5);
+    p = __builtin_elementwise_fma(p, r, c4);
+    p = __builtin_elementwise_fma(p, r, c3);
+    p = __builtin_elementwise_fma(p, r, c2);
+    p = __builtin_elementwise_fma(p, r, half);
+    f32x4 em1 = __builtin_elementwise_fma(p * r, r, r);
+    i32x4 k = __builtin_convertvector(kf, i32x4);
+    f32x4 sc = (f32x4)((k + 127) << 23);
+    return __builtin_elementwise_fma(sc, em1, sc - one);
 }
 
+// ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit for bit
 __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
-    f32x4 r;
-    r.x = act_fn(act, v.x); r.y = act_fn(act, v.y); r.z = act_fn(act, v.z); r.w = act_fn(act, v.w);
-    return r;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    i32x4 m = v > zero;
+    f32x4 pos = (f32x4)(((i32x4)v) & m);
+    if (act == AZG_ACT_ELU) {
+        f32x4 neg = (f32x4)(((i32x4)v) & ~m);
+        return pos + expm1f4(neg);
+    }
+    return pos;
 }
 
 __device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {
@@ -163,13 +206,20 @@ struct WRegs {
     f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
     f32x4 b[NREG > 0 ? NREG : 1][NTW];
     f32x4 wh[NTW];   // head weights of this wave's K-chunk
+    float w0[NTW];   // first layer (K <= 4: one k-step per tile)
+    f32x4 b0[NTW];
 };
 
 // The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  outs: [16 trees][16 outputs].
 // Activations: act buffers of HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand.
 template <int HP, int NREG>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
-                                            f32x4* parts, float* outs, int wave, int lane) {
+                                            f32x4* parts, float* outs, const float* s_bhead, int wave, int lane
+#ifdef AZG_STAMPS
+                                            , unsigned long long* st_acc
+#endif
+                                            ) {
+    STAMP(m0);
     constexpr int NTW = HP / 64;   // output tiles per wave
     constexpr int S4 = HP / 16;    // groups of 4 MFMA k-steps over a hidden vector
     // layer 0: K = in_dim <= 4 -> one k-step
@@ -178,12 +228,13 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             int nt = wave * NTW + i;
-            f32x4 acc = P.b0[nt * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, acc, 0, 0, 0);
+            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0);
             actA[nt * 64 + lane] = act4(P.act, acc);
         }
     }
     __syncthreads();
+    STAMP(m1);
+    STAMP_ADD(4, m0, m1);
     f32x4* in = actA;
     f32x4* out = actB;
     // hidden->hidden layers held in registers
@@ -193,15 +244,32 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             f32x4 acc[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i] = wr.b[l][i];
+            f32x4 bcur = in[lane];
 #pragma unroll
             for (int s4 = 0; s4 < S4; ++s4) {
-                f32x4 b = in[s4 * 64 + lane];
+                f32x4 bnext = bcur;
+                if (s4 + 1 < S4) bnext = in[(s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
+                __builtin_amdgcn_sched_barrier(0);                   // keep the ds_read above this block's MFMAs
+                // k-step outer, tile inner: consecutive MFMAs are independent chains (40-cycle dependent latency)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = mfma4(wr.w[l][i][s4], b, acc[i]);
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].x, bcur.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].y, bcur.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].z, bcur.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].w, bcur.w, acc[i], 0, 0, 0);
+                bcur = bnext;
             }
+            STAMP(m2);
 #pragma unroll
             for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
+            STAMP(m2b);
             __syncthreads();
+            STAMP(m3);
+            STAMP_ADD(5, m1, m2);
+            STAMP_ADD(6, m2, m2b);
+            STAMP_ADD(7, m2b, m3);
             f32x4* t = in; in = out; out = t;
         }
     } else {
@@ -212,14 +280,20 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             f32x4 acc[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i] = bb[(wave * NTW + i) * 64 + lane];
-#pragma unroll 4
+#pragma unroll 2
             for (int s4 = 0; s4 < S4; ++s4) {
                 f32x4 b = in[s4 * 64 + lane];
+                f32x4 a[NTW];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    f32x4 a = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
-                    acc[i] = mfma4(a, b, acc[i]);
-                }
+                for (int i = 0; i < NTW; ++i) a[i] = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
@@ -243,7 +317,7 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
         int tid = wave * 64 + lane;
         int tree = tid & 15, o = tid >> 4;
         if (o < P.n_out) {
-            float total = P.bhead[o];
+            float total = s_bhead[o];
             int idx = (o >> 2) * 16 + tree;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -281,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     __shared__ f32x4 s_parts[4 * 64];
     __shared__ float s_obsT[4 * 16];
     __shared__ float s_outs[16 * 16];
+    __shared__ float s_bhead[16];
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n] then pw_need [n_sims+2] (ints)
 
     const int tid = threadIdx.x;
@@ -296,8 +371,17 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
 
+    if (tid < 16) s_bhead[tid] = P.bhead[tid];
     // register-resident weights
     WRegs<HP, NREG> wr;
+    {
+        constexpr int NTW0 = HP / 64;
+#pragma unroll
+        for (int i = 0; i < NTW0; ++i) {
+            wr.w0[i] = P.W0[(wave * NTW0 + i) * 64 + lane];
+            wr.b0[i] = P.b0[(wave * NTW0 + i) * 64 + lane];
+        }
+    }
     if (NREG > 0) {
         constexpr int NTW = HP / 64, S4 = HP / 16;
 #pragma unroll
@@ -322,6 +406,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     double* state = P.state + tb * S;
     unsigned short* child = P.child + tb * P.Kp;
 
+#ifdef AZG_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     int nrec = 1;
     unsigned eps_draws = 0;
     int leaf = 0;
@@ -350,8 +437,15 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
 
     for (int sim = -1; sim < P.n_sims; ++sim) {
         // ================= network phase: evaluate the 16 pending leaves =================
+        STAMP(t_a);
         int any = __syncthreads_or(need_eval ? 1 : 0);
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, wave, lane);
+        STAMP(t_b);
+#ifdef AZG_STAMPS
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, s_bhead, wave, lane, st_acc);
+#else
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, s_bhead, wave, lane);
+#endif
+        STAMP(t_c);
 
         // ================= tree phase A: finish the evaluated leaf, back up =================
         if (live) {
@@ -433,6 +527,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         }
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
+        STAMP(t_d);
 
         // ================= tree phase B: next trace: select down, step the env, expand =================
         need_eval = false;
@@ -546,7 +641,15 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             }
         }
         __threadfence_block();
+        STAMP(t_e);
+        STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase
+        STAMP_ADD(1, t_b, t_c);   // network phase
+        STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
+        STAMP_ADD(3, t_d, t_e);   // select / step / expand
     }
+#ifdef AZG_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; ++i) P.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = st_acc[i];
+#endif
     if (live && sub == 0) P.n_rec[tree] = nrec;
 }
 
@@ -792,6 +895,11 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_child_state, B * K * e->S_env, e->dev_allocs));
     CK(dalloc(e, &e->d_rootV, B, e->dev_allocs));
     CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
+    {
+        unsigned long long* st;
+        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 4 * 8, e->dev_allocs));
+        e->P.stamps = st;
+    }
     std::vector<double> sq(e->tab_n);
     for (int n = 0; n < e->tab_n; ++n) sq[n] = std::sqrt((double)(n + 1));
     HK(hipMemcpy(d_pw, pw.data(), sizeof(int) * (ns + 2), hipMemcpyHostToDevice));
@@ -918,7 +1026,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
     // hidden->hidden layers that fit the register file stay there for the whole search
     int nhh = d->n_hidden - 1;
-    int regs = nhh * (HP * HP / 64);
+    int regs = nhh * (HP * HP / 256);   // VGPRs per lane: each of the 4 waves holds a quarter of every layer
     e->nreg = (nhh >= 1 && nhh <= 3 && regs <= 288) ? nhh : 0;
     const char* force = getenv("AZG_FORCE_STREAM_WEIGHTS");
     if (force && force[0] == '1') e->nreg = 0;
@@ -1073,6 +1181,17 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
         }
     }
     return AZG_OK;
+}
+
+// diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][8]; returns the number of rows
+int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
+    if (!e || !out) return AZG_E_INVALID;
+    size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 4;
+    if (rows > max_rows) rows = max_rows;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, e->P.stamps, rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (int)rows;
 }
 
 int azg_max_children(const azg_engine* e) { return e ? e->Kmax : AZG_E_INVALID; }

@@ -62,22 +62,24 @@ AZG_HD float azg_expf(float x) {
     return p * azg_u2f((uint32_t)(k + 127) << 23);
 }
 
-/* e^x - 1 */
+/* e^x - 1, branch-free: x = k ln2 + r, result = 2^k * expm1(r) + (2^k - 1) */
 AZG_HD float azg_expm1f(float x) {
-    float ax = x < 0.0f ? -x : x;
-    if (ax < 0.35f) {
-        float p = 2.75573192239858925e-6f;                 /* 1/9! */
-        p = AZG_FMAF(p, x, 2.48015873015873016e-5f);       /* 1/8! */
-        p = AZG_FMAF(p, x, 1.98412698412698413e-4f);
-        p = AZG_FMAF(p, x, 1.38888888888888894e-3f);
-        p = AZG_FMAF(p, x, 8.33333333333333322e-3f);
-        p = AZG_FMAF(p, x, 4.16666666666666644e-2f);
-        p = AZG_FMAF(p, x, 1.66666666666666657e-1f);
-        p = AZG_FMAF(p, x, 0.5f);
-        float x2 = x * x;
-        return AZG_FMAF(p, x2, x);
-    }
-    return azg_expf(x) - 1.0f;
+    float xc = x < -87.0f ? -87.0f : (x > 88.0f ? 88.0f : x);
+    const float magic = 12582912.0f;
+    float kf = AZG_FMAF(xc, 1.44269504088896341f, magic);
+    kf = kf - magic;
+    float r = AZG_FMAF(-kf, 0.693145751953125f, xc);
+    r = AZG_FMAF(-kf, 1.42860682030941723212e-6f, r);
+    float p = 1.98412698412698413e-4f;                     /* 1/5040 */
+    p = AZG_FMAF(p, r, 1.38888888888888894e-3f);
+    p = AZG_FMAF(p, r, 8.33333333333333322e-3f);
+    p = AZG_FMAF(p, r, 4.16666666666666644e-2f);
+    p = AZG_FMAF(p, r, 1.66666666666666657e-1f);
+    p = AZG_FMAF(p, r, 0.5f);
+    float em1 = AZG_FMAF(p * r, r, r);
+    int k = (int)kf;
+    float sc = azg_u2f((uint32_t)(k + 127) << 23);
+    return AZG_FMAF(sc, em1, sc - 1.0f);
 }
 
 /* tanh(z) = sign(z) * em1/(em1+2), em1 = e^{2|z|}-1 */

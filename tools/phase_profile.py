@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a simulation step spends its cycles (in-kernel s_memtime stamps, -DAZG_STAMPS build).
+Read the SHARES, not the absolute time (stamps serialise the schedule).  GPU box only:
+    make -C alphazero_gym_amd/csrc libazgym_hip_stamp.so && python tools/phase_profile.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "libazgym_hip_stamp.so")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import oracle_lib as O  # noqa: E402  (make_weights only)
+from alphazero_gym_amd import _capi, _native  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "pendulum"
+    B = 4096
+    if mode == "pendulum":
+        n_sims, hidden = 200, [256, 256]
+        e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=n_sims, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+        e.set_weights(_capi.make_desc(3, hidden, 2, "elu"), O.make_weights(34, 3, hidden, 2))
+    else:
+        n_sims, hidden = 100, [128, 128]
+        e = _native.HipEngine(env_id=0, mode=0, n_trees=B, n_sims=n_sims, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+        e.set_weights(_capi.make_desc(4, hidden, 2, "relu"), O.make_weights(34, 4, hidden, 2))
+    e.upload_roots(e.synthetic_roots())
+    for _ in range(3):
+        e.search_resident()
+    e.sync()
+    print("kernel ms", e.last_search_ms())
+    rows = (B + 15) // 16 * 4
+    buf = np.zeros((rows, 8), np.uint64)
+    lib = _native.lib()
+    lib.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+    n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows)
+    assert n == rows
+    names = ["barrier wait", "network (MLP)", "finish leaf + backup", "select/step/expand"]
+    tot = buf[:, :4].sum(1).mean()
+    for i, nm in enumerate(names):
+        v = buf[:, i].astype(np.float64)
+        print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
+    print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
+    for i, nm in zip(range(4, 8), ["  mlp: layer0 + barrier", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  mlp: hidden barrier"]):
+        v = buf[:, i].astype(np.float64)
+        print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  (register-weight layers only)")
+
+
+if __name__ == "__main__":
+    main()
