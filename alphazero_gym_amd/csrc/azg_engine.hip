@@ -32,18 +32,42 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// 32-byte "hot" record: everything selection and backup touch.  Record j = edge j + (once expanded) its child node.
-struct __attribute__((aligned(16))) Hot {
-    double Q;               // edge action value (Q_init = parent V)
-    double W;               // edge cumulative return
-    int edge_n;             // edge visit count
-    int node_n;             // node visit count
-    short parent;           // record of the parent node, -1 for the root
-    unsigned short n_child; // node: number of child edges
-    unsigned char flags;    // FLAG_EXPANDED | FLAG_TERMINAL
-    unsigned char pad[3];
+// Record j of a tree = edge j + (once expanded) the node that edge leads to; record 0 is the root.
+// "Hot" part: everything selection and the count/Q side of backup touch.  Two encodings:
+//   RecS (16 B) lives in LDS for the whole search when the tree fits (<= 255 records, counts < 65536),
+//   RecL (24 B) lives in global memory (any size); it is also the format trees are published in at the end of a search.
+struct __attribute__((aligned(16))) RecS {
+    double Q;                // edge action value (Q_init = parent V)
+    unsigned short edge_n;   // edge visit count
+    unsigned short node_n;   // node visit count
+    unsigned char parent;    // record of the parent node
+    unsigned char n_child;   // node: number of child edges
+    unsigned char flags;     // FLAG_EXPANDED | FLAG_TERMINAL
+    unsigned char first;     // discrete: record of child edge 0 (children are contiguous)
 };
-static_assert(sizeof(Hot) == 32, "Hot must be 32 bytes");
+struct __attribute__((aligned(8))) RecL {
+    double Q;
+    int edge_n;
+    int node_n;
+    short parent;
+    unsigned short n_child;
+    unsigned short first;
+    unsigned char flags;
+    unsigned char pad;
+};
+static_assert(sizeof(RecS) == 16, "RecS must be 16 bytes");
+static_assert(sizeof(RecL) == 24, "RecL must be 24 bytes");
+
+// "Cold" part of a node (global memory): read once when a child is expanded from it or an action is sampled at it
+struct __attribute__((aligned(16))) Cold {
+    double s[4];   // env state (Pendulum: theta, theta_dot, sin(theta) cached, unused)
+    double r;      // reward on arriving here (already divided by reward_scale in continuous mode)
+    float V;       // value estimate
+    float mu;      // continuous: cached squashed-Normal mean
+    float sg;      //             and standard deviation
+    float pad;
+};
+static_assert(sizeof(Cold) == 64, "Cold must be 64 bytes");
 
 struct KParams {
     int B, n_sims, R, Kp, A, nd, n_out, n_hidden, act, v1, tree_base, mode;
@@ -55,13 +79,12 @@ struct KParams {
     int tab_n;               // entries in sqrt_tab
     const double* roots;     // [B][S]
     const int* carry;        // [B]
-    Hot* hot;                // [B][R]
-    double* node_r;          // [B][R]
-    float* node_V;           // [B][R]
-    float* action;           // [B][R]
-    float* dist;             // [B][R][nd]
-    double* state;           // [B][R][S]
-    unsigned short* child;   // [B][R][Kp]
+    RecL* hot;               // [B][R]      published trees (and working storage when the tree does not fit LDS)
+    Cold* cold;              // [B][R]
+    double* edge_W;          // [B][R]      edge cumulative return
+    float* action;           // [B][R]      continuous: edge action
+    float* prior;            // [B][R]      discrete: edge prior
+    unsigned short* child;   // [B][R][Kp]  continuous: child record ids of a node, in creation order
     int* n_rec;              // [B]
     const int* pw_need;      // [n_sims+2]
     const double* sqrt_tab;  // [tab_n]  sqrt(n+1)
@@ -84,14 +107,17 @@ struct KParams {
 
 // ------------------------------------------------------------------------------------------------ environments
 
+// observation of a state; Pendulum also returns sin(theta) so that the node can cache it for its children's dynamics
 template <int ENV>
-__device__ __forceinline__ void env_obs(const double* s, float* obs) {
+__device__ __forceinline__ void env_obs(const double* s, float* obs, double* sn_out) {
     if (ENV == AZG_ENV_CARTPOLE) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
+        *sn_out = 0.0;
     } else {
         double sn, cs;
         azg_sincos(s[0], &sn, &cs);
         obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1]; obs[3] = 0.0f;
+        *sn_out = sn;
     }
 }
 
@@ -117,8 +143,8 @@ __device__ __forceinline__ void cartpole_step(const double* s, int action, doubl
     *reward = 1.0;
 }
 
-// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after
-__device__ __forceinline__ void pendulum_step(int v1, const double* s, float action, double* o, double* reward, int* done) {
+// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node
+__device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {
     const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
     const float max_torque = 2.0f;
     double th = s[0], thdot = s[1];
@@ -128,8 +154,7 @@ __device__ __forceinline__ void pendulum_step(int v1, const double* s, float act
     double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
     double newth, newthdot, sn, cs;
     if (v1) {
-        azg_sincos(th, &sn, &cs);
-        newthdot = thdot + (15.0 * sn + 3.0 * u) * dt;
+        newthdot = thdot + (15.0 * sn_th + 3.0 * u) * dt;
         newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
         newth = th + newthdot * dt;
     } else {
@@ -333,30 +358,131 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
 
 // ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
 
-// lane index (0..15) of the maximum, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
+// cross-lane moves inside a 16-lane row (one tree) on the DPP network: no LDS traffic, one VALU op each
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    unsigned long long u = azg_d2u(v);
+    unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)u), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(u >> 32));
+    return azg_u2d(((unsigned long long)hi << 32) | lo);
+}
+#define DPP_QUAD_XOR1 0xB1   // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E   // quad_perm:[2,3,0,1]
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+
+// lane index (0..15) of the maximum over the row, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
 __device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
-    double bu = valid ? u : -__builtin_huge_val();
-    int bi = valid ? sub : 99;
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-        double ou = __shfl_xor(bu, m, 16);
-        int oi = __shfl_xor(bi, m, 16);
-        if (ou > bu || (ou == bu && oi < bi)) { bu = ou; bi = oi; }
-    }
-    return bi;
+    double m = valid ? u : -__builtin_huge_val();
+    double o;
+    o = dpp_f64<DPP_QUAD_XOR1>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_QUAD_XOR2>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_ROW_ROR4>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_ROW_ROR8>(m); m = o > m ? o : m;
+    int c = (valid && u == m) ? sub : 99;
+    int t;
+    t = dpp_i32<DPP_QUAD_XOR1>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_QUAD_XOR2>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_ROW_ROR4>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_ROW_ROR8>(c); c = t < c ? t : c;
+    return c;
 }
 
-template <int ENV, int HP, int NREG>
+// storage of the hot part of one tree: LDS (RecS, 8-bit ids) or global memory (RecL, 16-bit ids)
+template <bool TLDS> struct TreeStore;
+template <> struct TreeStore<true> {
+    typedef RecS Rec;
+    typedef unsigned char Id;
+    Rec* hot; Id* child; float* prior;
+};
+template <> struct TreeStore<false> {
+    typedef RecL Rec;
+    typedef unsigned short Id;
+    Rec* hot; Id* child; float* prior;
+};
+
+template <typename Rec>
+__device__ __forceinline__ Rec make_edge(double Q, int parent) {
+    Rec h;
+    h.Q = Q; h.edge_n = 0; h.node_n = 0; h.parent = (decltype(h.parent))parent; h.n_child = 0; h.flags = 0; h.first = 0;
+    return h;
+}
+__device__ __forceinline__ void clear_pad(RecS&) {}
+__device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
+
+// MCTS.backprop (mcts.py:260-267) for one tree by its 16 lanes: the path is collected 16 levels at a time (lane d = d-th
+// record from the leaf), rewards / W are fetched in parallel, the discounted return is chained serially (its rounding
+// order is part of the contract), then every lane updates its own record.
+template <bool CONT, bool TLDS>
+__device__ __forceinline__ void backup(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int leaf, float V, int sub,
+                                       float gamma_f, double gamma) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    int j = leaf;
+    bool firstlvl = true, at_leaf = true;
+    double Rv = 0.0;
+    while (true) {
+        int mine = 0, cnt = 0, jj = j;
+        bool hit_root = false;
+        Rec mrec = ts.hot[jj];
+#pragma unroll 1
+        for (int d = 0; d < 16; ++d) {
+            Rec rr = ts.hot[jj];
+            if (sub == d) { mine = jj; mrec = rr; }
+            cnt = d + 1;
+            if (jj == 0) { hit_root = true; break; }
+            jj = rr.parent;
+        }
+        const bool is_edge = (sub < cnt) && (mine != 0);
+        double r = 0.0, W = 0.0;
+        if (is_edge) { r = cold[mine].r; W = edge_W[mine]; }
+        double myR = 0.0;
+        const int nedge = hit_root ? cnt - 1 : cnt;
+#pragma unroll 1
+        for (int d = 0; d < nedge; ++d) {
+            double rd = __shfl(r, d, 16);
+            double gR;
+            if (firstlvl) {
+                // continuous: V is a float32 0-d array and gamma a python scalar -> float32 product (NumPy >= 2);
+                // discrete: V is a python float -> float64 product
+                gR = CONT ? (double)(gamma_f * V) : gamma * (double)V;
+                firstlvl = false;
+            } else {
+                gR = gamma * Rv;
+            }
+            Rv = rd + gR;
+            if (sub == d) myR = Rv;
+        }
+        if (sub < cnt) {
+            if (is_edge) {
+                int en = (int)mrec.edge_n + 1;
+                double Wn = W + myR;
+                mrec.Q = Wn / (double)en;
+                mrec.edge_n = (decltype(mrec.edge_n))en;
+                edge_W[mine] = Wn;
+            }
+            if (!(at_leaf && sub == 0)) mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
+            ts.hot[mine] = mrec;
+        }
+        if (hit_root) break;
+        j = jj;
+        at_leaf = false;
+    }
+}
+
+template <int ENV, int HP, int NREG, bool TLDS>
 __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int S = CONT ? 2 : 4;
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    typedef typename TreeStore<TLDS>::Id Id;
     __shared__ f32x4 s_actA[HP / 16 * 64];
     __shared__ f32x4 s_actB[HP / 16 * 64];
     __shared__ f32x4 s_parts[4 * 64];
     __shared__ float s_obsT[4 * 16];
     __shared__ float s_outs[16 * 16];
     __shared__ float s_bhead[16];
-    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n] then pw_need [n_sims+2] (ints)
+    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, then (TLDS) the 16 trees' hot records
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -370,8 +496,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     int* s_pw = (int*)(s_dyn + P.tab_n);
     for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
-
     if (tid < 16) s_bhead[tid] = P.bhead[tid];
+
     // register-resident weights
     WRegs<HP, NREG> wr;
     {
@@ -398,13 +524,24 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     }
 
     const size_t tb = (size_t)(live ? tree : 0) * P.R;
-    Hot* hot = P.hot + tb;
-    double* node_r = P.node_r + tb;
-    float* node_V = P.node_V + tb;
+    Cold* cold = P.cold + tb;
+    double* edge_W = P.edge_W + tb;
     float* action = P.action + tb;
-    float* dist = P.dist + tb * P.nd;
-    double* state = P.state + tb * S;
-    unsigned short* child = P.child + tb * P.Kp;
+    TreeStore<TLDS> ts;
+    if (TLDS) {
+        // per tree: R records of 16 B, then (continuous) R x Kp child ids or (discrete) R priors
+        size_t off = ((size_t)P.tab_n * 8 + (size_t)(P.n_sims + 2) * 4 + 15) / 16 * 16;
+        size_t per = (size_t)P.R * 16 + (CONT ? (size_t)P.R * P.Kp : (size_t)P.R * 4);
+        per = (per + 15) / 16 * 16;
+        char* base = (char*)s_dyn + off + per * tl;
+        ts.hot = (Rec*)base;
+        ts.child = (Id*)(base + (size_t)P.R * 16);
+        ts.prior = (float*)(base + (size_t)P.R * 16);
+    } else {
+        ts.hot = (Rec*)(P.hot + tb);
+        ts.child = (Id*)(P.child + tb * P.Kp);
+        ts.prior = P.prior + tb;
+    }
 
 #ifdef AZG_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -413,23 +550,32 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     unsigned eps_draws = 0;
     int leaf = 0;
     bool need_eval = live;
+    // progressive-widening noise: lane `sub` holds the N(0,1) draw for record kbase + sub
+    int kbase = 1;
+    float eps_c = 0.0f;
+    if (CONT && live) eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(kbase + sub));
 
     // ---- root (initialize_search + evaluation / add_value_estimate: mcts.py:364-383, 437; 589-600, 672)
     {
-        double rs[S];
+        double rs[S], sn;
 #pragma unroll
         for (int k = 0; k < S; ++k) rs[k] = live ? P.roots[(size_t)tree * S + k] : 0.0;
         float obs[4];
-        env_obs<ENV>(rs, obs);
+        env_obs<ENV>(rs, obs, &sn);
         if (live && sub == 0) {
-            Hot h;
-            h.Q = 0.0; h.W = 0.0; h.edge_n = 0; h.node_n = P.carry[tree]; h.parent = -1; h.n_child = 0;
-            h.flags = FLAG_EXPANDED; h.pad[0] = h.pad[1] = h.pad[2] = 0;
-            hot[0] = h;
-            node_r[0] = 0.0;
-            action[0] = 0.0f;
+            Rec h = make_edge<Rec>(0.0, 0);
+            h.node_n = (decltype(h.node_n))P.carry[tree];
+            h.flags = FLAG_EXPANDED;
+            clear_pad(h);
+            ts.hot[0] = h;
+            Cold c;
 #pragma unroll
-            for (int k = 0; k < S; ++k) state[k] = rs[k];
+            for (int k = 0; k < 4; ++k) c.s[k] = k < S ? rs[k] : 0.0;
+            if (CONT) c.s[2] = sn;
+            c.r = 0.0; c.V = 0.0f; c.mu = 0.0f; c.sg = 0.0f; c.pad = 0.0f;
+            cold[0] = c;
+            edge_W[0] = 0.0;
+            if (CONT) action[0] = 0.0f;
         }
         if (sub < 4) s_obsT[sub * 16 + tl] = live ? obs[sub] : 0.0f;
     }
@@ -457,7 +603,22 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     float ls = s_outs[tl * 16 + 2];
                     ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
                     float sg = azg_expf(ls);
-                    if (sub == 0) { node_V[leaf] = V; dist[leaf * 2] = mu; dist[leaf * 2 + 1] = sg; }
+                    if (sub == 0) { cold[leaf].V = V; cold[leaf].mu = mu; cold[leaf].sg = sg; }
+                    if (sim < 0) {
+                        // add_pw_action(root) before the first trace (mcts.py:673)
+                        int k = nrec++;
+                        float eps = __shfl(eps_c, k - kbase, 16);
+                        float a = P.bound_f * azg_tanhf(mu + sg * eps);
+                        if (sub == 0) {
+                            Rec h = make_edge<Rec>((double)V, 0);
+                            clear_pad(h);
+                            ts.hot[k] = h;
+                            edge_W[k] = 0.0;
+                            action[k] = a;
+                            ts.child[0] = (Id)k;
+                            ts.hot[0].n_child = 1;
+                        }
+                    }
                 } else {
                     // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
                     const int A = P.A;
@@ -469,60 +630,22 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     nrec += A;
                     if (sub < A) {
                         float pr = azg_expf(s_outs[tl * 16 + 1 + sub] - mx) / sum;
-                        dist[leaf * P.nd + sub] = pr;
-                        Hot h;
-                        h.Q = (double)V; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = (short)leaf; h.n_child = 0;
-                        h.flags = 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
-                        hot[k0 + sub] = h;
-                        action[k0 + sub] = (float)sub;
-                        child[leaf * P.Kp + sub] = (unsigned short)(k0 + sub);
+                        Rec h = make_edge<Rec>((double)V, leaf);
+                        clear_pad(h);
+                        ts.hot[k0 + sub] = h;
+                        ts.prior[k0 + sub] = pr;
+                        edge_W[k0 + sub] = 0.0;
                     }
-                    if (sub == 0) { node_V[leaf] = V; hot[leaf].n_child = (unsigned short)A; }
+                    if (sub == 0) {
+                        cold[leaf].V = V;
+                        ts.hot[leaf].n_child = (decltype(ts.hot[leaf].n_child))A;
+                        ts.hot[leaf].first = (decltype(ts.hot[leaf].first))k0;
+                    }
                 }
-            } else if (sim >= 0) {
-                V = node_V[leaf];
             }
             if (sim >= 0) {
-                // MCTS.backprop (mcts.py:260-267); all 16 lanes walk redundantly, lane 0 stores
-                int j = leaf;
-                bool first = true;
-                double Rv = 0.0;
-                Hot hj = hot[j];
-                while (hj.parent >= 0) {
-                    double gR;
-                    if (first) {
-                        gR = CONT ? (double)(P.gamma_f * V) : P.gamma * (double)V;
-                        first = false;
-                    } else {
-                        gR = P.gamma * Rv;
-                    }
-                    Rv = node_r[j] + gR;
-                    int en = hj.edge_n + 1;
-                    double W = hj.W + Rv;
-                    double Q = W / (double)en;
-                    if (sub == 0) { hot[j].Q = Q; hot[j].W = W; hot[j].edge_n = en; }
-                    j = hj.parent;
-                    hj = hot[j];
-                    if (sub == 0) hot[j].node_n = hj.node_n + 1;
-                }
-            } else if (CONT) {
-                // add_pw_action(root) before the first trace (mcts.py:673)
-                float mu = s_outs[tl * 16 + 1];
-                float ls = s_outs[tl * 16 + 2];
-                ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
-                float sg = azg_expf(ls);
-                int k = nrec++;
-                float eps = azg_normal(P.seed, gtree, P.search_idx, (unsigned)k);
-                float a = P.bound_f * azg_tanhf(mu + sg * eps);
-                if (sub == 0) {
-                    Hot h;
-                    h.Q = (double)V; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = 0; h.n_child = 0; h.flags = 0;
-                    h.pad[0] = h.pad[1] = h.pad[2] = 0;
-                    hot[k] = h;
-                    action[k] = a;
-                    child[0] = (unsigned short)k;
-                    hot[0].n_child = 1;
-                }
+                if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
+                backup<CONT, TLDS>(ts, cold, edge_W, leaf, V, sub, P.gamma_f, P.gamma);
             }
         }
         if (sim == P.n_sims - 1) break;
@@ -532,34 +655,36 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         // ================= tree phase B: next trace: select down, step the env, expand =================
         need_eval = false;
         if (live) {
+            if (CONT && nrec >= kbase + 16) {
+                kbase = nrec;
+                eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(kbase + sub));
+            }
             int p = 0;
+            Rec hp = ts.hot[0];
+            Cold cp = cold[0];   // cold part of the current node, prefetched one level ahead
             while (true) {
-                Hot hp = hot[p];
-                int K = hp.n_child;
+                const int K = hp.n_child;
                 int chosen;
-                unsigned cflags;
-                float cact;
+                float cact = 0.0f;
                 bool widen = false;
                 if (CONT) {
-                    int nn = hp.node_n < P.n_sims + 1 ? hp.node_n : P.n_sims + 1;
+                    int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
                     widen = s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
                 }
+                Rec hc;
                 if (widen) {
                     // MCTSContinuous.add_pw_action (mcts.py:625-654)
                     chosen = nrec++;
-                    float mu = dist[p * 2], sg = dist[p * 2 + 1];
-                    float Vp = node_V[p];
-                    float eps = azg_normal(P.seed, gtree, P.search_idx, (unsigned)chosen);
-                    cact = P.bound_f * azg_tanhf(mu + sg * eps);
-                    cflags = 0;
+                    float eps = __shfl(eps_c, chosen - kbase, 16);
+                    cact = P.bound_f * azg_tanhf(cp.mu + cp.sg * eps);
+                    hc = make_edge<Rec>((double)cp.V, p);
+                    clear_pad(hc);
                     if (sub == 0) {
-                        Hot h;
-                        h.Q = (double)Vp; h.W = 0.0; h.edge_n = 0; h.node_n = 0; h.parent = (short)p; h.n_child = 0; h.flags = 0;
-                        h.pad[0] = h.pad[1] = h.pad[2] = 0;
-                        hot[chosen] = h;
+                        ts.hot[chosen] = hc;
+                        edge_W[chosen] = 0.0;
                         action[chosen] = cact;
-                        child[p * P.Kp + K] = (unsigned short)chosen;
-                        hot[p].n_child = (unsigned short)(K + 1);
+                        ts.child[p * P.Kp + K] = (Id)chosen;
+                        ts.hot[p].n_child = (decltype(hp.n_child))(K + 1);
                     }
                 } else {
                     int pick = -1;
@@ -568,28 +693,24 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                         azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, eps_draws++, AZG_STREAM_EPS);
                         if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
                     }
-                    double sq = s_sqrt[hp.node_n];
-                    int c = 0;
-                    unsigned fl = 0;
-                    double U = 0.0;
-                    // children are scanned 16 at a time
+                    const double sq = s_sqrt[hp.node_n];
                     int win_c = 0;
-                    unsigned win_f = 0;
                     double win_u = 0.0;
                     bool have = false;
-                    for (int base = 0; base < K; base += 16) {
-                        int i = base + sub;
-                        bool valid = i < K;
+                    for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
+                        const int i = base + sub;
+                        const bool valid = i < K;
+                        int c = 0;
+                        double U = 0.0;
                         if (valid) {
-                            c = child[p * P.Kp + i];
-                            Hot hc = hot[c];
-                            fl = hc.flags;
-                            double ratio = sq / (double)(hc.edge_n + 1);
+                            c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
+                            Rec h = ts.hot[c];
+                            double ratio = sq / (double)((int)h.edge_n + 1);
                             if (CONT) {
-                                U = hc.Q + P.c_uct * ratio;
+                                U = h.Q + P.c_uct * ratio;
                             } else {
-                                float pc = dist[p * P.nd + i] * P.c_uct_f;   // float32 product (NumPy>=2 promotion)
-                                U = hc.Q + (double)pc * ratio;
+                                float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+                                U = h.Q + (double)pc * ratio;
                             }
                         }
                         int w;
@@ -597,42 +718,40 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                         else w = argmax16(U, valid, sub);
                         if (w >= 0) {
                             int wc = __shfl(c, w, 16);
-                            unsigned wf = __shfl(fl, w, 16);
                             double wu = __shfl(U, w, 16);
-                            if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_f = wf; win_u = wu; have = true; }
+                            if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
                         }
                     }
                     chosen = win_c;
-                    cflags = win_f;
-                    cact = 0.0f;
+                    hc = ts.hot[chosen];
                 }
-                if (cflags & FLAG_EXPANDED) {
+                if (hc.flags & FLAG_EXPANDED) {
                     p = chosen;
-                    if (cflags & FLAG_TERMINAL) { leaf = p; break; }
+                    hp = hc;
+                    if (hc.flags & FLAG_TERMINAL) { leaf = p; break; }
+                    cp = cold[p];
                     continue;
                 }
                 // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
-                double st[S], ns[S], r;
+                double ns[S], r, sn;
                 int done;
-#pragma unroll
-                for (int k = 0; k < S; ++k) st[k] = state[p * S + k];
-                if (!widen) cact = action[chosen];
                 if (CONT) {
-                    pendulum_step(P.v1, st, cact, ns, &r, &done);
+                    if (!widen) cact = action[chosen];
+                    pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
                     r = r / P.reward_scale;   // mcts.py:687
                 } else {
-                    cartpole_step(st, (int)cact, ns, &r, &done);
+                    cartpole_step(cp.s, chosen - (int)hp.first, ns, &r, &done);
                 }
                 float obs[4];
-                env_obs<ENV>(ns, obs);
+                env_obs<ENV>(ns, obs, &sn);
                 if (sub == 0) {
+                    Cold c;
 #pragma unroll
-                    for (int k = 0; k < S; ++k) state[chosen * S + k] = ns[k];
-                    node_r[chosen] = r;
-                    hot[chosen].node_n = 0;
-                    hot[chosen].n_child = 0;
-                    hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
-                    if (done) node_V[chosen] = 0.0f;
+                    for (int k = 0; k < 4; ++k) c.s[k] = k < S ? ns[k] : 0.0;
+                    if (CONT) c.s[2] = sn;
+                    c.r = r; c.V = 0.0f; c.mu = 0.0f; c.sg = 0.0f; c.pad = 0.0f;
+                    cold[chosen] = c;
+                    ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
                 }
                 leaf = chosen;
                 need_eval = !done;
@@ -650,47 +769,71 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
 #ifdef AZG_STAMPS
     if (lane == 0) for (int i = 0; i < 8; ++i) P.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = st_acc[i];
 #endif
-    if (live && sub == 0) P.n_rec[tree] = nrec;
+    if (live) {
+        if (sub == 0) P.n_rec[tree] = nrec;
+        if (TLDS) {
+            // publish the LDS-resident tree in the global format
+            RecL* gh = P.hot + tb;
+            for (int j = sub; j < nrec; j += 16) {
+                Rec h = ts.hot[j];
+                RecL o;
+                o.Q = h.Q; o.edge_n = h.edge_n; o.node_n = h.node_n; o.parent = (short)h.parent; o.n_child = h.n_child;
+                o.first = h.first; o.flags = h.flags; o.pad = 0;
+                gh[j] = o;
+                if (CONT) {
+                    for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = ts.child[j * P.Kp + i];
+                } else {
+                    P.prior[tb + j] = ts.prior[j];
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ result gathering
 
-// MCTS.return_results (mcts.py:269-307): one thread per tree
+// MCTS.return_results (mcts.py:269-307): one thread per tree, from the published (global) trees
 __global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt, int* nch,
                                int* child_n, double* child_state, float* root_V, float* root_dist) {
     int tree = blockIdx.x * blockDim.x + threadIdx.x;
     if (tree >= P.B) return;
     size_t tb = (size_t)tree * P.R;
-    const Hot* hot = P.hot + tb;
+    const RecL* hot = P.hot + tb;
     const unsigned short* child = P.child + tb * P.Kp;
-    int nc = hot[0].n_child;
+    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
+    const RecL root = hot[0];
+    int nc = root.n_child;
     long tot = 0;
-    for (int a = 0; a < nc; ++a) tot += hot[child[a]].edge_n;
+    for (int a = 0; a < nc; ++a) tot += hot[cont ? child[a] : root.first + a].edge_n;
     double qmax = 0.0, onp = 0.0;
     for (int a = 0; a < Kmax; ++a) {
-        int k = a < nc ? child[a] : -1;
-        Hot h;
-        if (k >= 0) h = hot[k];
-        actions[(size_t)tree * Kmax + a] = k >= 0 ? P.action[tb + k] : 0.0f;
+        int k = a < nc ? (cont ? (int)child[a] : (int)root.first + a) : -1;
+        RecL h = hot[k >= 0 ? k : 0];
+        actions[(size_t)tree * Kmax + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
         counts[(size_t)tree * Kmax + a] = k >= 0 ? h.edge_n : 0;
         Q[(size_t)tree * Kmax + a] = k >= 0 ? h.Q : 0.0;
         bool ex = k >= 0 && (h.flags & FLAG_EXPANDED);
         child_n[(size_t)tree * Kmax + a] = ex ? h.node_n : -1;
-        for (int s = 0; s < P.S; ++s) child_state[((size_t)tree * Kmax + a) * P.S + s] = ex ? P.state[(tb + k) * P.S + s] : 0.0;
+        for (int s = 0; s < P.S; ++s) child_state[((size_t)tree * Kmax + a) * P.S + s] = ex ? P.cold[tb + k].s[s] : 0.0;
         if (k >= 0) {
             if (a == 0 || h.Q > qmax) qmax = h.Q;
-            if (P.mode == AZG_MODE_DISCRETE) onp += ((double)h.edge_n / (double)tot) * h.Q;
+            if (!cont) onp += ((double)h.edge_n / (double)tot) * h.Q;
         }
     }
-    if (P.mode == AZG_MODE_CONTINUOUS) {
+    if (cont) {
         // reference quirk (mcts.py:111 with Q of shape (K,1)): the K x K outer product is summed
         for (int a = 0; a < nc; ++a)
             for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
     }
     vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
     nch[tree] = nc;
-    root_V[tree] = P.node_V[tb];
-    for (int d = 0; d < P.nd; ++d) root_dist[(size_t)tree * P.nd + d] = P.dist[tb * P.nd + d];
+    root_V[tree] = P.cold[tb].V;
+    if (cont) {
+        root_dist[(size_t)tree * 2] = P.cold[tb].mu;
+        root_dist[(size_t)tree * 2 + 1] = P.cold[tb].sg;
+    } else {
+        for (int d = 0; d < P.nd; ++d) root_dist[(size_t)tree * P.nd + d] = P.prior[tb + root.first + d];
+    }
 }
 
 __global__ void math_selftest_kernel(int fn_id, const double* in, double* out, size_t n) {
@@ -735,6 +878,8 @@ struct azg_engine {
     azg_config cfg;
     int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
     int mlp_ready, HP, n_hidden, n_out, act, nreg;
+    int tree_lds;            // 1: hot records live in LDS during the search
+    size_t dyn_lds;          // dynamic LDS bytes per workgroup
     float ls_min, ls_max;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -774,31 +919,41 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
     return AZG_OK;
 }
 
-template <int ENV, int HP, int NREG>
-static hipError_t launch(azg_engine* e, size_t dyn) {
+template <int ENV, int HP, int NREG, bool TLDS>
+static hipError_t launch_t(azg_engine* e) {
     dim3 grid((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG), block(256);
-    hipLaunchKernelGGL((search_kernel<ENV, HP, NREG>), grid, block, dyn, e->stream, e->P);
+    auto kern = search_kernel<ENV, HP, NREG, TLDS>;
+    if (e->dyn_lds > 48 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dyn_lds);
+        if (rc != hipSuccess) return rc;
+    }
+    hipLaunchKernelGGL(kern, grid, block, e->dyn_lds, e->stream, e->P);
     return hipGetLastError();
 }
 
+template <int ENV, int HP, int NREG>
+static hipError_t launch(azg_engine* e) {
+    return e->tree_lds ? launch_t<ENV, HP, NREG, true>(e) : launch_t<ENV, HP, NREG, false>(e);
+}
+
 template <int ENV>
-static hipError_t dispatch(azg_engine* e, size_t dyn) {
+static hipError_t dispatch(azg_engine* e) {
     const int HP = e->HP, NR = e->nreg;
     if (HP == 64) {
-        if (NR == 1) return launch<ENV, 64, 1>(e, dyn);
-        if (NR == 2) return launch<ENV, 64, 2>(e, dyn);
-        if (NR == 3) return launch<ENV, 64, 3>(e, dyn);
-        return launch<ENV, 64, 0>(e, dyn);
+        if (NR == 1) return launch<ENV, 64, 1>(e);
+        if (NR == 2) return launch<ENV, 64, 2>(e);
+        if (NR == 3) return launch<ENV, 64, 3>(e);
+        return launch<ENV, 64, 0>(e);
     }
     if (HP == 128) {
-        if (NR == 1) return launch<ENV, 128, 1>(e, dyn);
-        if (NR == 2) return launch<ENV, 128, 2>(e, dyn);
-        if (NR == 3) return launch<ENV, 128, 3>(e, dyn);
-        return launch<ENV, 128, 0>(e, dyn);
+        if (NR == 1) return launch<ENV, 128, 1>(e);
+        if (NR == 2) return launch<ENV, 128, 2>(e);
+        if (NR == 3) return launch<ENV, 128, 3>(e);
+        return launch<ENV, 128, 0>(e);
     }
     if (HP == 256) {
-        if (NR == 1) return launch<ENV, 256, 1>(e, dyn);
-        return launch<ENV, 256, 0>(e, dyn);
+        if (NR == 1) return launch<ENV, 256, 1>(e);
+        return launch<ENV, 256, 0>(e);
     }
     return hipErrorInvalidValue;
 }
@@ -861,7 +1016,22 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     }
     if (e->R > 32767) { delete e; return fail(nullptr, AZG_E_UNSUPPORTED, "tree too large: records per tree must be < 32768"); }
     e->Kp = (e->Kmax + 15) / 16 * 16;
-    e->tab_n = 4 * ns + 4;
+    // sqrt(n+1) table: node visit counts reach n_sims (+ the carried root count in discrete mode, <= 3 n_sims)
+    e->tab_n = cfg->mode == AZG_MODE_CONTINUOUS ? ns + 2 : 4 * ns + 4;
+    {
+        // LDS-resident hot records when a tree fits: 8-bit record ids, 16-bit counts, <= 16 children per node
+        size_t off = ((size_t)e->tab_n * 8 + (size_t)(ns + 2) * 4 + 15) / 16 * 16;
+        size_t per = (size_t)e->R * 16 + (cfg->mode == AZG_MODE_CONTINUOUS ? (size_t)e->R * e->Kp : (size_t)e->R * 4);
+        per = (per + 15) / 16 * 16;
+        size_t with_trees = off + per * TREES_PER_WG;
+        // static LDS of the largest kernel (HP = 256): two activation buffers + head partials + small arrays
+        const size_t static_max = 2 * 256 * 64 + 4096 + 1024 + 256 + 64 + 64;
+        bool fits = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536 && with_trees + static_max <= 160 * 1024;
+        const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
+        if (force && force[0] == '1') fits = false;
+        e->tree_lds = fits ? 1 : 0;
+        e->dyn_lds = fits ? with_trees : off;
+    }
     if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
 #define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
@@ -871,14 +1041,13 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     KParams& P = e->P;
     memset(&P, 0, sizeof(P));
     const size_t B = (size_t)cfg->n_trees, R = (size_t)e->R;
-    Hot* hot; double* node_r; float* node_V; float* action; float* dist; double* state; unsigned short* child; int* n_rec;
+    RecL* hot; Cold* cold; double* edge_W; float* action; float* prior; unsigned short* child; int* n_rec;
     int* d_pw; double* d_sq;
     CK(dalloc(e, &hot, B * R, e->dev_allocs));
-    CK(dalloc(e, &node_r, B * R, e->dev_allocs));
-    CK(dalloc(e, &node_V, B * R, e->dev_allocs));
+    CK(dalloc(e, &cold, B * R, e->dev_allocs));
+    CK(dalloc(e, &edge_W, B * R, e->dev_allocs));
     CK(dalloc(e, &action, B * R, e->dev_allocs));
-    CK(dalloc(e, &dist, B * R * e->nd, e->dev_allocs));
-    CK(dalloc(e, &state, B * R * e->S_env, e->dev_allocs));
+    CK(dalloc(e, &prior, B * R, e->dev_allocs));
     CK(dalloc(e, &child, B * R * e->Kp, e->dev_allocs));
     CK(dalloc(e, &n_rec, B, e->dev_allocs));
     CK(dalloc(e, &d_pw, (size_t)ns + 2, e->dev_allocs));
@@ -904,7 +1073,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     for (int n = 0; n < e->tab_n; ++n) sq[n] = std::sqrt((double)(n + 1));
     HK(hipMemcpy(d_pw, pw.data(), sizeof(int) * (ns + 2), hipMemcpyHostToDevice));
     HK(hipMemcpy(d_sq, sq.data(), sizeof(double) * e->tab_n, hipMemcpyHostToDevice));
-    HK(hipMemset(hot, 0, B * R * sizeof(Hot)));
+    HK(hipMemset(hot, 0, B * R * sizeof(RecL)));
     HK(hipMemset(e->d_carry, 0, B * sizeof(int)));
     P.B = cfg->n_trees; P.n_sims = ns; P.R = e->R; P.Kp = e->Kp; P.A = cfg->num_actions; P.nd = e->nd;
     P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
@@ -912,7 +1081,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;
     P.seed = cfg->seed; P.S = e->S_env; P.tab_n = e->tab_n;
     P.roots = e->d_roots; P.carry = e->d_carry;
-    P.hot = hot; P.node_r = node_r; P.node_V = node_V; P.action = action; P.dist = dist; P.state = state; P.child = child;
+    P.hot = hot; P.cold = cold; P.edge_W = edge_W; P.action = action; P.prior = prior; P.child = child;
     P.n_rec = n_rec; P.pw_need = d_pw; P.sqrt_tab = d_sq;
     *out = e;
     return AZG_OK;
@@ -1063,9 +1232,8 @@ int azg_search_resident(azg_engine* e) {
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     e->P.search_idx = e->search_idx;
-    size_t dyn = sizeof(double) * (size_t)e->tab_n + sizeof(int) * (size_t)(e->cfg.n_sims + 2);
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    hipError_t rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e, dyn) : dispatch<AZG_ENV_PENDULUM_V1>(e, dyn);
+    hipError_t rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e) : dispatch<AZG_ENV_PENDULUM_V1>(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;
@@ -1153,30 +1321,33 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     size_t B = e->cfg.n_trees, R = e->R;
-    std::vector<Hot> hot(B * R);
+    std::vector<RecL> hot(B * R);
+    std::vector<Cold> cold(B * R);
     std::vector<int> nrec(B);
-    std::vector<double> nr(B * R);
-    std::vector<float> nv(B * R), ac(B * R);
-    HIPCHK(e, hipMemcpy(hot.data(), e->P.hot, B * R * sizeof(Hot), hipMemcpyDeviceToHost));
+    std::vector<double> ew(B * R);
+    std::vector<float> ac(B * R);
+    HIPCHK(e, hipMemcpy(hot.data(), e->P.hot, B * R * sizeof(RecL), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(cold.data(), e->P.cold, B * R * sizeof(Cold), hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(nrec.data(), e->P.n_rec, B * 4, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(nr.data(), e->P.node_r, B * R * 8, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(nv.data(), e->P.node_V, B * R * 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(ew.data(), e->P.edge_W, B * R * 8, hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(ac.data(), e->P.action, B * R * 4, hipMemcpyDeviceToHost));
+    const bool cont = e->cfg.mode == AZG_MODE_CONTINUOUS;
+    const int A = e->cfg.num_actions;
     for (size_t i = 0; i < B; ++i) {
         if (n_records) n_records[i] = nrec[i];
         for (size_t j = 0; j < R; ++j) {
             size_t o = i * R + j;
             bool in = (int)j < nrec[i];
-            const Hot& h = hot[o];
+            const RecL& h = hot[o];
             bool ex = in && (h.flags & FLAG_EXPANDED);
-            if (parent) parent[o] = in ? h.parent : 0;
+            if (parent) parent[o] = in ? (j == 0 ? -1 : h.parent) : 0;
             if (edge_n) edge_n[o] = in ? h.edge_n : 0;
-            if (edge_W) edge_W[o] = in ? h.W : 0.0;
+            if (edge_W) edge_W[o] = in ? ew[o] : 0.0;
             if (edge_Q) edge_Q[o] = in ? h.Q : 0.0;
-            if (edge_action) edge_action[o] = in ? ac[o] : 0.0f;
+            if (edge_action) edge_action[o] = in ? (cont ? ac[o] : (j == 0 ? 0.0f : (float)((j - 1) % A))) : 0.0f;
             if (node_n) node_n[o] = in ? h.node_n : 0;
-            if (node_r) node_r[o] = ex ? nr[o] : 0.0;
-            if (node_V) node_V[o] = ex ? nv[o] : 0.0f;
+            if (node_r) node_r[o] = ex ? cold[o].r : 0.0;
+            if (node_V) node_V[o] = ex ? cold[o].V : 0.0f;
             if (node_flags) node_flags[o] = in ? h.flags : 0;
         }
     }

@@ -94,16 +94,23 @@ CONFIGS = [
     (0, 0, [128, 128], "relu", 100, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
     (0, 0, [64, 64], "elu", 60, dict(c_uct=20.0, gamma=0.95, epsilon=0.1, num_actions=2, v_target="on_policy")),
     (0, 0, [256, 256], "relu", 80, dict(c_uct=5.0, gamma=0.99, num_actions=2)),
+    # trees too large for LDS residency (> 255 records): global-memory tree storage
+    (2, 1, [64, 64], "elu", 300, dict(c_uct=0.05, gamma=1.0)),
+    (0, 0, [64, 64], "relu", 200, dict(c_uct=8.0, gamma=0.98, num_actions=2)),
 ]
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("stream", [0, 1])
-def test_hip_bit_exact_vs_oracle(native, cfg, stream, monkeypatch):
-    """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical."""
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree"])
+def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
+    """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
+    Variants force the fallback code paths: weights streamed from L2 instead of registers, trees in global memory
+    instead of LDS."""
     env, mode, hidden, act, n_sims, extra = cfg
-    if stream:
+    if variant == "stream_weights":
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
+    if variant == "global_tree":
+        monkeypatch.setenv("AZG_FORCE_GLOBAL_TREE", "1")
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
     in_dim, n_dist = (3, 2) if mode == 1 else (4, 2)
