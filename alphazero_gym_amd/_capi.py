@@ -112,8 +112,21 @@ def bind(lib, prefix):
 
 
 def policy_blob(policy):
-    """Flatten a torch policy (network/policies.py) into (AzgMlpDesc, float32 blob) in state_dict order."""
+    """Flatten a torch policy into (AzgMlpDesc, float32 blob) in state_dict order.  Works for this package's policies
+    and for the reference's DiscretePolicy / DiagonalNormalPolicy objects alike (same attribute names:
+    trunk, value_head, dist_head, hidden_dimensions, state_dim; alphazero/network/policies.py:101-120, 238-259)."""
     hidden = list(policy.hidden_dimensions)
+    linears, acts = [], set()
+    for mod in policy.trunk:
+        name = type(mod).__name__
+        if name == "Linear":
+            linears.append(mod)
+        elif name in ("ReLU", "ELU"):
+            acts.add(name.lower())
+        else:
+            raise NotImplementedError(f"trunk module {name}: the engine implements Linear + ReLU/ELU trunks only")
+    if len(acts) != 1 or len(linears) != len(hidden):
+        raise NotImplementedError("unsupported trunk structure")
     desc = AzgMlpDesc()
     desc.struct_size = C.sizeof(AzgMlpDesc)
     desc.in_dim = policy.state_dim
@@ -121,15 +134,12 @@ def policy_blob(policy):
     for i, h in enumerate(hidden):
         desc.hidden[i] = h
     desc.n_dist = policy.dist_head.out_features
-    desc.activation = ACT[policy.nonlinearity]
+    desc.activation = ACT[acts.pop()]
     desc.log_std_min = float(getattr(policy, "log_param_min", -5.0))
     desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
     parts = []
-    for mod in policy.trunk:
-        if hasattr(mod, "weight") and mod.weight.dim() == 2:
-            parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
-    parts += [policy.value_head.weight.detach().cpu().numpy().ravel(), policy.value_head.bias.detach().cpu().numpy().ravel()]
-    parts += [policy.dist_head.weight.detach().cpu().numpy().ravel(), policy.dist_head.bias.detach().cpu().numpy().ravel()]
+    for mod in linears + [policy.value_head, policy.dist_head]:
+        parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
     blob = np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
     return desc, blob
 

@@ -1,0 +1,186 @@
+"""Agents with the reference's surface (alphazero/agent/agents.py): ``act`` = one engine search + the final action
+rule, ``update``/``train`` = the PyTorch optimiser step over replay-buffer minibatches, ``reset_mcts``,
+``mcts_forward`` and the read-only properties the run scripts log."""
+import random
+from abc import ABC, abstractmethod
+from collections import defaultdict
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..config import instantiate
+from ..helpers import stable_normalizer
+from ..search.mcts import MCTSContinuous, MCTSDiscrete
+from .buffers import ReplayBuffer
+from .losses import A0CLoss
+
+Obs = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]
+
+
+class Agent(ABC):
+    """agents.py:19-184.  The four *_cfg arguments are `_target_` mappings (hydra DictConfigs work: they are Mappings)
+    or already-built objects."""
+
+    def __init__(self, policy_cfg, mcts_cfg, loss_cfg, optimizer_cfg, final_selection: str, train_epochs: int,
+                 grad_clip: float, device: str) -> None:
+        self.device = torch.device(device)
+        self.nn = instantiate(policy_cfg).to(self.device)
+        self.mcts = instantiate(mcts_cfg, model=self.nn)
+        loss = instantiate(loss_cfg)
+        self.loss = loss.to(self.device) if hasattr(loss, "to") else loss
+        self.optimizer = instantiate(optimizer_cfg, params=self.nn.parameters())
+        self.final_selection = final_selection
+        self.train_epochs = train_epochs
+        self.clip = grad_clip
+
+    @abstractmethod
+    def act(self, Env): ...
+
+    @abstractmethod
+    def update(self, obs: Obs) -> Dict[str, float]: ...
+
+    @property
+    def action_dim(self) -> int:
+        return self.nn.action_dim
+
+    @property
+    def state_dim(self) -> int:
+        return self.nn.state_dim
+
+    @property
+    def n_hidden_layers(self) -> int:
+        return self.nn.n_hidden_layers
+
+    @property
+    def n_hidden_units(self) -> int:
+        return self.nn.n_hidden_units
+
+    @property
+    def n_rollouts(self) -> int:
+        return self.mcts.n_rollouts
+
+    @property
+    def learning_rate(self) -> float:
+        return self.optimizer.param_groups[0]["lr"]
+
+    @property
+    def c_uct(self) -> float:
+        return self.mcts.c_uct
+
+    @property
+    def gamma(self) -> float:
+        return self.mcts.gamma
+
+    def reset_mcts(self, root_state: np.ndarray) -> None:
+        """agents.py:146-155"""
+        self.mcts.root_node = None
+        self.mcts.root_state = root_state
+
+    def train(self, buffer: ReplayBuffer) -> Dict[str, Any]:
+        """One pass of minibatch updates per epoch over the reshuffled buffer (agents.py:157-184); like the reference,
+        the per-key sums are returned (its division by the batch count has no effect)."""
+        buffer.reshuffle()
+        running_loss: Dict[str, Any] = defaultdict(float)
+        for _ in range(self.train_epochs):
+            for obs in buffer:
+                loss = self.update(obs)
+                for key, val in loss.items():
+                    running_loss[key] += val
+        return running_loss
+
+    def _step(self, loss_dict) -> Dict[str, float]:
+        loss_dict["loss"].backward()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.nn.parameters(), self.clip)
+        self.optimizer.step()
+        return {key: float(value.detach()) if hasattr(value, "detach") else float(value) for key, value in loss_dict.items()}
+
+
+class DiscreteAgent(Agent):
+    """agents.py:187-392"""
+
+    def __init__(self, policy_cfg, mcts_cfg, loss_cfg, optimizer_cfg, final_selection: str, train_epochs: int, grad_clip: float,
+                 temperature: float, device: str) -> None:
+        super().__init__(policy_cfg=policy_cfg, loss_cfg=loss_cfg, mcts_cfg=mcts_cfg, optimizer_cfg=optimizer_cfg,
+                         final_selection=final_selection, train_epochs=train_epochs, grad_clip=grad_clip, device=device)
+        assert isinstance(self.mcts, MCTSDiscrete)
+        self.temperature = temperature
+
+    def act(self, Env, deterministic: bool = False):
+        """Search, then sample the action from the (temperature-scaled) visit-count or Q distribution (agents.py:257-303).
+        Returns (action, state, actions, counts, Qs, V)."""
+        self.mcts.search(Env=Env)
+        state, actions, counts, Qs, V = self.mcts.return_results(self.final_selection)
+        pi = stable_normalizer(Qs if self.final_selection == "max_value" else counts, self.temperature)
+        action = pi.argmax() if deterministic else np.random.choice(len(pi), p=pi)
+        return action, state, actions, counts, Qs, V
+
+    def mcts_forward(self, action: int, node: np.ndarray) -> None:
+        self.mcts.forward(action, node)
+
+    def update(self, obs: Obs) -> Dict[str, float]:
+        """agents.py:319-392"""
+        for param in self.nn.parameters():
+            param.grad = None
+        states, actions, counts, _, V_target = obs
+        states_t = torch.from_numpy(states).float().to(self.device)
+        values_t = torch.from_numpy(V_target).unsqueeze(dim=1).float().to(self.device)
+        if isinstance(self.loss, A0CLoss):
+            actions_t = torch.from_numpy(actions).float().to(self.device)
+            counts += 1   # in place, like the reference (agents.py:364): keeps log(counts) finite
+            counts_t = torch.from_numpy(counts).float().to(self.device)
+            log_probs, entropy, V_hat = self.nn.get_train_data(states_t, actions_t)
+            loss_dict = self.loss(log_probs=log_probs, counts=counts_t, entropy=entropy, V=values_t, V_hat=V_hat)
+        else:
+            probs_t = F.softmax(torch.from_numpy(counts).float(), dim=-1).to(self.device)
+            dist, V_hat = self.nn(states_t)
+            loss_dict = self.loss(dist.logits, probs_t, V_hat, values_t)
+        return self._step(loss_dict)
+
+
+class ContinuousAgent(Agent):
+    """agents.py:395-603"""
+
+    def __init__(self, policy_cfg, mcts_cfg, loss_cfg, optimizer_cfg, final_selection: str, epsilon: float, train_epochs: int,
+                 grad_clip: float, device: str) -> None:
+        super().__init__(policy_cfg=policy_cfg, loss_cfg=loss_cfg, mcts_cfg=mcts_cfg, optimizer_cfg=optimizer_cfg,
+                         final_selection=final_selection, train_epochs=train_epochs, grad_clip=grad_clip, device=device)
+        assert isinstance(self.mcts, MCTSContinuous)
+        self.epsilon = epsilon
+
+    @property
+    def action_limit(self) -> float:
+        return self.nn.action_bound
+
+    def epsilon_greedy(self, actions: np.ndarray, values: np.ndarray) -> np.ndarray:
+        """agents.py:471-490"""
+        if random.random() < self.epsilon:
+            return np.random.choice(actions)[np.newaxis]
+        return actions[values.argmax()][np.newaxis]
+
+    def act(self, Env):
+        """Search, then the most visited (or highest-Q) root action, first index on ties (agents.py:492-537)."""
+        self.mcts.search(Env=Env)
+        state, actions, counts, Qs, V = self.mcts.return_results(self.final_selection)
+        values = Qs if self.final_selection == "max_value" else counts
+        actions1 = np.atleast_1d(actions)
+        if self.epsilon == 0:
+            action = actions1[values.argmax()][np.newaxis]
+        else:
+            action = self.epsilon_greedy(actions=actions1, values=values)
+        return action, state, actions, counts, Qs, V
+
+    def update(self, obs: Obs) -> Dict[str, float]:
+        """agents.py:539-603"""
+        for param in self.nn.parameters():
+            param.grad = None
+        states, actions, counts, _, V_target = obs
+        actions_t = torch.from_numpy(actions).float().to(self.device)
+        states_t = torch.from_numpy(states).float().to(self.device)
+        counts_t = torch.from_numpy(counts).float().to(self.device)
+        values_t = torch.from_numpy(V_target).unsqueeze(dim=1).float().to(self.device)
+        log_probs, entropy, V_hat = self.nn.get_train_data(states_t, actions_t)
+        loss_dict = self.loss(log_probs=log_probs, counts=counts_t, entropy=entropy, V=values_t, V_hat=V_hat)
+        return self._step(loss_dict)

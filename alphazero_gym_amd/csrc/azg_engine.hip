@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     }
 
 #ifdef AZG_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int nrec = 1;
     unsigned eps_draws = 0;
@@ -643,6 +643,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     }
                 }
             }
+            STAMP(t_c2);
+            STAMP_ADD(8, t_c, t_c2);    // finish leaf (before backup)
             if (sim >= 0) {
                 if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
                 backup<CONT, TLDS>(ts, cold, edge_W, leaf, V, sub, P.gamma_f, P.gamma);
@@ -733,6 +735,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     continue;
                 }
                 // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
+                STAMP(t_x);
+                STAMP_ADD(9, t_d, t_x);    // descent until the expansion point
                 double ns[S], r, sn;
                 int done;
                 if (CONT) {
@@ -756,6 +760,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                 leaf = chosen;
                 need_eval = !done;
                 if (sub < 4) s_obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
+                STAMP(t_y);
+                STAMP_ADD(10, t_x, t_y);   // env step + node creation
                 break;
             }
         }
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         STAMP_ADD(3, t_d, t_e);   // select / step / expand
     }
 #ifdef AZG_STAMPS
-    if (lane == 0) for (int i = 0; i < 8; ++i) P.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = st_acc[i];
+    if (lane == 0) for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * 4 + wave) * 16 + i] = st_acc[i];
 #endif
     if (live) {
         if (sub == 0) P.n_rec[tree] = nrec;
@@ -1066,7 +1072,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
     {
         unsigned long long* st;
-        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 4 * 8, e->dev_allocs));
+        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 4 * 16, e->dev_allocs));
         e->P.stamps = st;
     }
     std::vector<double> sq(e->tab_n);
@@ -1354,14 +1360,14 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     return AZG_OK;
 }
 
-// diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][8]; returns the number of rows
+// diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
     size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 4;
     if (rows > max_rows) rows = max_rows;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, e->P.stamps, rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(out, e->P.stamps, rows * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return (int)rows;
 }
 

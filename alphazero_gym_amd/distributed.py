@@ -1,0 +1,59 @@
+"""Multi-GPU self-play: one process per GPU, trees sharded by global tree id, no collective inside the search.
+
+The reference is single-process; independent games shard embarrassingly.  Rank g of G owns the global
+tree ids [g*B/G, (g+1)*B/G); RNG streams and synthetic roots are keyed by the global id, so a tree's result does not
+depend on G.  Exactly two collectives exist (RCCL over xGMI when the backend is "nccl"; "gloo" in CPU tests):
+an all-gather of replay rows after self-play and a broadcast of the updated weights after the optimiser step."""
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) global tree ids of `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_replay_rows(states: np.ndarray, actions: np.ndarray, counts: np.ndarray, Q: np.ndarray, v_target: np.ndarray) -> torch.Tensor:
+    """One float32 row per game: state | actions[K] | counts[K] | Q[K] | V_target  (196 B for Pendulum, K = 15)."""
+    B = states.shape[0]
+    return torch.from_numpy(np.concatenate([
+        states.reshape(B, -1).astype(np.float32), actions.reshape(B, -1).astype(np.float32), counts.reshape(B, -1).astype(np.float32),
+        Q.reshape(B, -1).astype(np.float32), v_target.reshape(B, 1).astype(np.float32)], axis=1))
+
+
+def unpack_replay_rows(rows: torch.Tensor, state_dim: int, K: int):
+    r = rows.cpu().numpy()
+    s = r[:, :state_dim]
+    a = r[:, state_dim:state_dim + K]
+    c = r[:, state_dim + K:state_dim + 2 * K]
+    q = r[:, state_dim + 2 * K:state_dim + 3 * K]
+    return s, a, c, q, r[:, -1]
+
+
+def gather_replay_rows(rows: torch.Tensor, device=None) -> torch.Tensor:
+    """All-gather equally sized per-rank row blocks into [world*B, row] ordered by rank (= by global tree id)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows
+    rows = rows.to(device) if device is not None else rows
+    out = [torch.empty_like(rows) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rows.contiguous())
+    return torch.cat(out, dim=0)
+
+
+def broadcast_weights(model: torch.nn.Module, src: int = 0) -> None:
+    """Rank `src` trained; everyone else receives the parameters (one flat buffer: KBs to a few MB, latency-bound)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params: List[torch.Tensor] = [p.data for p in model.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.copy_(flat[off:off + n].view_as(p))
+        off += n

@@ -1,0 +1,148 @@
+"""Policy/value networks for the optimiser step (PyTorch) with the reference's constructor arguments, attribute names
+and inference methods (alphazero/network/policies.py).  The search itself never calls these modules: the engine
+reads their weights (alphazero_gym_amd._capi.policy_blob) and evaluates the MLP on the GPU's matrix cores.
+
+Supported: DiscretePolicy (policies.py:163-352) and DiagonalNormalPolicy (policies.py:355-499).  The GMM and Beta
+heads (policies.py:502-803) are not built yet."""
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .distributions import SquashedNormal
+
+_ACTIVATIONS = {"relu": nn.ReLU, "elu": nn.ELU}
+
+
+def _trunk(in_dim: int, hidden: List[int], nonlinearity: str, layernorm: bool) -> nn.Sequential:
+    if layernorm:
+        raise NotImplementedError("layernorm=True is not supported by the MI355X engine yet")
+    key = nonlinearity.lower().replace(" ", "")
+    if key not in _ACTIVATIONS:
+        raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the engine implements relu and elu")
+    layers, k = [], in_dim
+    for h in hidden:
+        layers += [nn.Linear(k, h), _ACTIVATIONS[key]()]
+        k = h
+    return nn.Sequential(*layers)
+
+
+class _PolicyBase(nn.Module):
+    def _setup(self, representation_dim, action_dim, hidden_dimensions, nonlinearity, layernorm):
+        assert hidden_dimensions, "Hidden dimensions can't be empty."
+        self.state_dim = representation_dim
+        self.action_dim = action_dim
+        self.hidden_dimensions = list(hidden_dimensions)
+        self.hidden_layers = len(hidden_dimensions)
+        self.nonlinearity = nonlinearity.lower().replace(" ", "")
+        self.layernorm = layernorm
+        self.trunk = _trunk(representation_dim, self.hidden_dimensions, nonlinearity, layernorm)
+        self.value_head = nn.Linear(self.hidden_dimensions[-1], 1)
+
+    @property
+    def n_hidden_layers(self) -> int:
+        return self.hidden_layers
+
+    @property
+    def n_hidden_units(self) -> int:
+        return sum(self.hidden_dimensions)
+
+
+class DiscretePolicy(_PolicyBase):
+    distribution_type = "Categorical"
+
+    def __init__(self, representation_dim: int, action_dim: int, num_actions: int, hidden_dimensions: List[int],
+                 nonlinearity: str, layernorm: bool = False):
+        super().__init__()
+        self._setup(representation_dim, action_dim, hidden_dimensions, nonlinearity, layernorm)
+        self.num_actions = num_actions
+        self.dist_head = nn.Linear(self.hidden_dimensions[-1], num_actions)
+
+    def _get_dist_params(self, x):
+        h = self.trunk(x)
+        return self.dist_head(h), self.value_head(h)
+
+    def forward(self, x):
+        logits, V_hat = self._get_dist_params(x)
+        return torch.distributions.Categorical(logits=logits), V_hat
+
+    def get_train_data(self, states, actions):
+        """log-probs [B, num_actions], entropy [B, num_actions], V_hat [B, 1] (policies.py:319-338)."""
+        logits, V_hat = self._get_dist_params(states)
+        num_actions = actions.shape[1]
+        pi_hat = torch.distributions.Categorical(logits=logits.unsqueeze(dim=1).repeat((1, num_actions, 1)))
+        return pi_hat.log_prob(actions), pi_hat.entropy(), V_hat
+
+    @torch.no_grad()
+    def predict_V(self, x) -> np.ndarray:
+        _, V_hat = self._get_dist_params(x)
+        return V_hat.detach().cpu().numpy()
+
+    @torch.no_grad()
+    def predict_pi(self, x) -> np.ndarray:
+        logits, _ = self._get_dist_params(x)
+        return F.softmax(logits, dim=-1).detach().cpu().numpy()
+
+
+class DiagonalNormalPolicy(_PolicyBase):
+    distribution_type = "Normal"
+
+    def __init__(self, representation_dim: int, action_dim: int, action_bound: Optional[float], hidden_dimensions: List[int],
+                 nonlinearity: str, layernorm: bool = False, log_param_min: float = -5, log_param_max: float = 2):
+        super().__init__()
+        self._setup(representation_dim, action_dim, hidden_dimensions, nonlinearity, layernorm)
+        self.action_bound = action_bound
+        self.log_param_min = log_param_min
+        self.log_param_max = log_param_max
+        self.dist_head = nn.Linear(self.hidden_dimensions[-1], 2 * action_dim)
+
+    @property
+    def bounds(self) -> np.ndarray:
+        if self.action_bound is None:
+            return np.array([-np.inf, np.inf], dtype=np.float32)
+        return np.array([-self.action_bound, self.action_bound], dtype=np.float32)
+
+    def forward(self, x):
+        h = self.trunk(x)
+        V_hat = self.value_head(h)
+        mu, log_std = self.dist_head(h).chunk(2, dim=-1)
+        log_std = torch.clamp(log_std, min=self.log_param_min, max=self.log_param_max)
+        return mu, log_std.exp(), V_hat
+
+    def _dist(self, mu, sigma):
+        if self.action_bound:
+            return SquashedNormal(mu, sigma, self.action_bound)
+        return torch.distributions.Normal(mu, sigma)
+
+    def get_train_data(self, states, actions):
+        """log-probs [B, K], entropy estimate [B], V_hat [B, 1] (policies.py:466-486)."""
+        mu, sigma, V_hat = self(states)
+        log_probs = self._dist(mu, sigma).log_prob(actions)
+        return log_probs, -log_probs.mean(dim=-1), V_hat
+
+    @torch.no_grad()
+    def predict_V(self, x) -> np.ndarray:
+        return self.value_head(self.trunk(x)).detach().cpu().numpy()
+
+    @torch.no_grad()
+    def sample_action(self, x) -> np.ndarray:
+        mu, sigma, _ = self(x)
+        return self._dist(mu, sigma).sample().detach().cpu().numpy()
+
+
+def make_policy(representation_dim: int, action_dim: int, distribution: str, hidden_dimensions: List[int], nonlinearity: str,
+                num_components: Optional[int] = None, num_actions: Optional[int] = None, action_bound: Optional[float] = None,
+                layernorm: bool = False, log_param_min: float = -5, log_param_max: float = 2):
+    """Factory with the reference's signature (policies.py:806-916)."""
+    distribution = distribution.lower().replace(" ", "")
+    if distribution == "discrete":
+        return DiscretePolicy(representation_dim, action_dim, int(num_actions), hidden_dimensions, nonlinearity, layernorm)
+    if distribution == "beta":
+        raise NotImplementedError("GeneralizedBetaPolicy is not built (the reference marks it as not working, README.md:21-22)")
+    assert num_components
+    if num_components > 1:
+        raise NotImplementedError("DiagonalGMMPolicy (num_components > 1) is not built yet; use num_components=1 (squashed Normal)")
+    return DiagonalNormalPolicy(representation_dim, action_dim, action_bound, hidden_dimensions, nonlinearity, layernorm,
+                                log_param_min, log_param_max)

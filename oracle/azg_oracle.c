@@ -705,3 +705,8 @@ int azo_env_step(int env_id, const double* state, float action, double* next, do
 }
 
 int azo_env_obs(int env_id, const double* state, float* obs) { env_obs(env_id, state, obs); return AZG_OK; }
+
+void azo_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+    azg_u32x4 r = azg_philox4x32(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}

@@ -386,6 +386,102 @@ def run_t3():
     return out
 
 
+def run_t4():
+    """Agent level: the reference's DiscreteAgent.act / ContinuousAgent.act (agents.py:257-303, 492-537) on top of the
+    T1 machinery (oracle-MLP evaluator, engine noise), built without hydra by filling the attributes __init__ would set."""
+    import random as pyrandom
+    from alphazero.agent.agents import ContinuousAgent, DiscreteAgent
+    out = {}
+    seed = 34
+    # continuous
+    hidden = [256, 256]
+    eng = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=25, c_uct=0.05, gamma=1.0, c_pw=1, kappa=0.5, seed=seed)
+    eng.set_weights(_capi.make_desc(3, hidden, 2, "elu"), O.make_weights(34, 3, hidden, 2))
+    ag = object.__new__(ContinuousAgent)
+    ag.final_selection = "max_visit"; ag.epsilon = 0
+    env = PendulumEnv(state=[1.0, 0.2], version=1)
+    rows = []
+    for t in range(3):
+        model = OracleModel(eng, seed, 0, t, 2.0)
+        RM.random = EngineRandom(seed, 0, t)
+        COUNTER["n"] = 0
+        ag.mcts = RM.MCTSContinuous(model=model, n_rollouts=25, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                                    V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
+        rs = np.asarray(env.azg_state()).copy()
+        action, s, actions, counts, Qs, V = ag.act(env)
+        rows.append(dict(root=rs, action=action, state=s, actions=actions, counts=counts, Qs=Qs, V=np.asarray(V)))
+        env.step(action)
+    for k in rows[0]:
+        out["c_" + k] = np.stack([r[k] for r in rows])
+    out["c_dtypes"] = np.array(repr({k: (str(np.asarray(v).dtype), np.asarray(v).shape) for k, v in rows[0].items()}))
+    # discrete, deterministic final action + tree reuse through mcts_forward
+    hidden = [128, 128]
+    eng = O.OracleEngine(env_id=0, mode=0, n_trees=1, n_sims=30, c_uct=25.0, gamma=0.97, num_actions=2, seed=seed)
+    eng.set_weights(_capi.make_desc(4, hidden, 2, "relu"), O.make_weights(5, 4, hidden, 2, scale=2.0))
+    ag = object.__new__(DiscreteAgent)
+    ag.final_selection = "max_visits"; ag.temperature = 1.0
+    env = CartPoleEnv(state=[0.01, -0.02, 0.03, 0.04])
+    ag.mcts = RM.MCTSDiscrete(model=None, num_actions=2, n_rollouts=30, c_uct=25.0, gamma=0.97, epsilon=0.0,
+                              V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
+    rows = []
+    for t in range(4):
+        ag.mcts.model = OracleModel(eng, seed, 0, t, 2.0)
+        RM.random = EngineRandom(seed, 0, t)
+        COUNTER["n"] = 0
+        rs = np.asarray(env.azg_state()).copy()
+        action, s, actions, counts, Qs, V = ag.act(env, deterministic=True)
+        rows.append(dict(root=rs, action=np.asarray(action), state=s, actions=actions, counts=counts, Qs=Qs, V=np.asarray(V),
+                         pi=np.asarray(__import__("alphazero.helpers", fromlist=["x"]).stable_normalizer(counts, 1.0))))
+        obs, r, done, _ = env.step(int(action))
+        ag.mcts_forward(int(action), obs)
+    for k in rows[0]:
+        out["d_" + k] = np.stack([r[k] for r in rows])
+    out["d_dtypes"] = np.array(repr({k: (str(np.asarray(v).dtype), np.asarray(v).shape) for k, v in rows[0].items()}))
+    return out
+
+
+def run_t5():
+    """Training side: get_train_data + the three losses of the reference on fixed batches (agents.py:319-392, 539-603)."""
+    from alphazero.agent.losses import A0CLoss, A0CLossTuned, AlphaZeroLoss
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(77))
+    hidden = [64, 64]
+    blob = O.make_weights(21, 3, hidden, 2)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    set_policy_weights(pol, blob, 3, hidden, 2)
+    B, K = 16, 5
+    states = rng.uniform(-1, 1, (B, 3)).astype(np.float32)
+    actions = rng.uniform(-1.9, 1.9, (B, K)).astype(np.float32)
+    counts = rng.integers(1, 9, (B, K)).astype(np.float32)
+    V = rng.uniform(-1, 0, (B, 1)).astype(np.float32)
+    lp, ent, vh = pol.get_train_data(torch.from_numpy(states), torch.from_numpy(actions))
+    out.update(c_states=states, c_actions=actions, c_counts=counts, c_V=V, c_log_probs=lp.detach().numpy(), c_entropy=ent.detach().numpy(),
+               c_V_hat=vh.detach().numpy())
+    l = A0CLoss(tau=0.1, policy_coeff=0.1, alpha=0.5, value_coeff=1, reduction="mean")
+    d = l(log_probs=lp, counts=torch.from_numpy(counts), entropy=ent, V=torch.from_numpy(V), V_hat=vh)
+    out["c_a0c"] = np.array([float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss")])
+    lt = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0, device="cpu")
+    d = lt(log_probs=lp, counts=torch.from_numpy(counts), entropy=ent, V=torch.from_numpy(V), V_hat=vh)
+    out["c_a0c_tuned"] = np.array([float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss")] + [float(lt.alpha)])
+    # discrete
+    blob = O.make_weights(22, 4, hidden, 2)
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu", num_actions=2)
+    set_policy_weights(pol, blob, 4, hidden, 2)
+    states = rng.uniform(-1, 1, (B, 4)).astype(np.float32)
+    actions = np.tile(np.arange(2, dtype=np.float32), (B, 1))
+    counts = rng.integers(0, 20, (B, 2)).astype(np.float32)
+    V = rng.uniform(0, 10, (B, 1)).astype(np.float32)
+    lp, ent, vh = pol.get_train_data(torch.from_numpy(states), torch.from_numpy(actions))
+    logits, vh2 = pol._get_dist_params(torch.from_numpy(states))
+    out.update(d_states=states, d_actions=actions, d_counts=counts, d_V=V, d_log_probs=lp.detach().numpy(), d_entropy=ent.detach().numpy(),
+               d_V_hat=vh.detach().numpy())
+    az = AlphaZeroLoss(policy_coeff=1.0, value_coeff=0.5, reduction="mean")
+    d = az(logits, torch.softmax(torch.from_numpy(counts), dim=-1), vh2, torch.from_numpy(V))
+    out["d_az"] = np.array([float(d[k]) for k in ("loss", "policy_loss", "value_loss")])
+    return out
+
+
 def main():
     for name, case in T1_CASES.items():
         TIES["n"] = 0
@@ -400,6 +496,12 @@ def main():
     TIES["n"] = 0
     t3 = run_t3()
     np.savez_compressed(os.path.join(HERE, "t3_end_to_end.npz"), **t3)
+    t4 = run_t4()
+    np.savez_compressed(os.path.join(HERE, "t4_agent_act.npz"), **t4)
+    print("t4", t4["c_dtypes"], t4["d_dtypes"], t4["d_action"].tolist(), t4["d_counts"].tolist())
+    t5 = run_t5()
+    np.savez_compressed(os.path.join(HERE, "t5_training.npz"), **t5)
+    print("t5", t5["c_a0c"], t5["c_a0c_tuned"], t5["d_az"])
     print("t3 ties", TIES["n"], "c_counts[0]", t3["c_counts"][0].tolist(), "d_counts", t3["d_counts"].tolist())
 
 

@@ -1,0 +1,78 @@
+"""CPU, world_size 2 over gloo: the N>1 path (tree sharding by global id, replay all-gather, weight broadcast).
+The engine is the oracle test double here; on the GPU box the same code runs over RCCL with the HIP engine."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from alphazero_gym_amd import _capi, distributed as D
+
+B_TOTAL, N_SIMS = 10, 40
+KW = dict(env_id=2, mode=1, n_sims=N_SIMS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+
+
+def _search(n_trees, base):
+    e = O.OracleEngine(n_trees=n_trees, tree_id_base=base, **KW)
+    e.set_weights(_capi.make_desc(3, [64, 64], 2, "elu"), O.make_weights(34, 3, [64, 64], 2))
+    roots = e.synthetic_roots()
+    e.search(roots)
+    r = e.results()
+    e.close()
+    return roots, r
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = D.shard_range(B_TOTAL, rank, world)
+    roots, r = _search(hi - lo, lo)
+    rows = D.pack_replay_rows(roots, r["actions"], r["counts"], r["Q"], r["v_target"])
+    allrows = D.gather_replay_rows(rows)
+    model = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.fill_(float(rank + 1))
+    D.broadcast_weights(model, src=0)
+    ok = all(bool((p == 1.0).all()) for p in model.parameters())
+    if rank == 0:
+        q.put((allrows.numpy(), ok))
+    else:
+        q.put((None, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_every_tree_once():
+    for n in (1, 7, 10, 4096, 32768):
+        for w in (1, 2, 3, 4, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_selfplay_equals_single_process():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in got)                       # weight broadcast reached every rank
+    rows = [g for g, _ in got if g is not None][0]
+    roots, r = _search(B_TOTAL, 0)                        # the same 10 games in one process
+    want = D.pack_replay_rows(roots, r["actions"], r["counts"], r["Q"], r["v_target"]).numpy()
+    np.testing.assert_array_equal(rows, want)             # per-tree results do not depend on the number of ranks
+    s_, a_, c_, q_, v_ = D.unpack_replay_rows(torch.from_numpy(rows), 2, r["actions"].shape[1])
+    np.testing.assert_array_equal(c_.sum(1), np.full(B_TOTAL, N_SIMS))

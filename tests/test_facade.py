@@ -1,0 +1,204 @@
+"""Host side of the drop-in boundary: MCTSDiscrete / MCTSContinuous / DiscreteAgent / ContinuousAgent against the tuples
+the reference's agents returned (tier T4 goldens), the training step against the reference's losses (T5), buffer,
+helpers and config plumbing.
+
+CPU runs substitute the C oracle for the HIP engine *as a test double* (same C ABI, prefix azo_) so that the Python host
+logic is exercised without a GPU; the `gpu`-marked variants run the identical assertions through libazgym_hip.so."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import parity_util as P
+from alphazero_gym_amd import _capi, config
+from alphazero_gym_amd.agent.agents import ContinuousAgent, DiscreteAgent
+from alphazero_gym_amd.agent.buffers import ReplayBuffer
+from alphazero_gym_amd.agent.losses import A0CLoss, A0CLossTuned, AlphaZeroLoss
+from alphazero_gym_amd.envs import CartPoleEnv, PendulumEnv
+from alphazero_gym_amd.helpers import argmax, stable_normalizer
+from alphazero_gym_amd.network.policies import make_policy
+from alphazero_gym_amd.search.mcts import MCTSContinuous, MCTSDiscrete
+
+
+def load_blob(pol, blob):
+    p = 0
+    lin = [m for m in pol.trunk if isinstance(m, torch.nn.Linear)] + [pol.value_head, pol.dist_head]
+    for m in lin:
+        o, i = m.weight.shape
+        m.weight.data = torch.from_numpy(blob[p:p + o * i].reshape(o, i).copy()); p += o * i
+        m.bias.data = torch.from_numpy(blob[p:p + o].copy()); p += o
+    assert p == blob.size
+
+
+BACKENDS = ["oracle_double", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request, monkeypatch):
+    from alphazero_gym_amd import _native
+    if request.param == "oracle_double":
+        monkeypatch.setattr(_native, "HipEngine", O.OracleEngine)
+    else:
+        _native.lib()
+    return request.param
+
+
+def _cont_agent():
+    pol_cfg = dict(_target_="alphazero.network.policies.make_policy", representation_dim=3, action_dim=1, distribution="normal",
+                   hidden_dimensions=[256, 256], nonlinearity="elu", num_components=1, action_bound=2.0)
+    mcts_cfg = dict(_target_="alphazero.search.mcts.MCTSContinuous", n_rollouts=25, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                    V_target_policy="off_policy", device="cpu", root_state=None)
+    loss_cfg = dict(_target_="alphazero.agent.losses.A0CLossTuned", action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1,
+                    value_coeff=1, reduction="mean", grad_clip=0, device="cpu")
+    opt_cfg = dict(_target_="torch.optim.RMSprop", lr=0.001, alpha=0.9, eps=1e-10)
+    ag = ContinuousAgent(policy_cfg=pol_cfg, mcts_cfg=mcts_cfg, loss_cfg=loss_cfg, optimizer_cfg=opt_cfg, final_selection="max_visit",
+                         epsilon=0, train_epochs=1, grad_clip=0, device="cpu")
+    load_blob(ag.nn, O.make_weights(34, 3, [256, 256], 2))
+    return ag
+
+
+def test_continuous_agent_act_matches_reference(backend):
+    z = np.load(os.path.join(P.GOLDEN, "t4_agent_act.npz"))
+    ag = _cont_agent()
+    env = PendulumEnv(state=[1.0, 0.2], version=1)
+    dt = ast.literal_eval(str(z["c_dtypes"]))
+    for t in range(z["c_action"].shape[0]):
+        np.testing.assert_allclose(env.azg_state(), z["c_root"][t], atol=1e-12)
+        ag.reset_mcts(env._get_obs())
+        action, s, actions, counts, Qs, V = ag.act(env)
+        got = dict(action=action, state=s, actions=actions, counts=counts, Qs=Qs, V=np.asarray(V))
+        for k, v in got.items():
+            assert (str(np.asarray(v).dtype), np.asarray(v).shape) == dt[k], (k, np.asarray(v).dtype, np.asarray(v).shape, dt[k])
+        np.testing.assert_array_equal(counts, z["c_counts"][t])
+        np.testing.assert_allclose(actions, z["c_actions"][t], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(Qs, z["c_Qs"][t], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(V, z["c_V"][t], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(action, z["c_action"][t], rtol=1e-6, atol=1e-7)
+        env.step(action)
+
+
+def test_discrete_agent_act_and_tree_reuse_match_reference(backend):
+    z = np.load(os.path.join(P.GOLDEN, "t4_agent_act.npz"))
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[128, 128], nonlinearity="relu", num_actions=2)
+    load_blob(pol, O.make_weights(5, 4, [128, 128], 2, scale=2.0))
+    env = CartPoleEnv(state=[0.01, -0.02, 0.03, 0.04])
+    mcts_cfg = dict(_target_="alphazero_gym_amd.search.mcts.MCTSDiscrete", num_actions=2, n_rollouts=30, c_uct=25.0, gamma=0.97,
+                    epsilon=0.0, V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
+    ag = DiscreteAgent(policy_cfg=pol, mcts_cfg=mcts_cfg, loss_cfg=AlphaZeroLoss(1.0, 1.0, "mean"),
+                       optimizer_cfg=dict(_target_="torch.optim.Adam", lr=1e-3), final_selection="max_visits", train_epochs=1,
+                       grad_clip=0, temperature=1.0, device="cpu")
+    dt = ast.literal_eval(str(z["d_dtypes"]))
+    for t in range(z["d_action"].shape[0]):
+        np.testing.assert_allclose(env.azg_state(), z["d_root"][t], atol=1e-12)
+        action, s, actions, counts, Qs, V = ag.act(env, deterministic=True)
+        got = dict(action=np.asarray(action), state=s, actions=actions, counts=counts, Qs=Qs, V=np.asarray(V))
+        for k, v in got.items():
+            assert (str(np.asarray(v).dtype), np.asarray(v).shape) == dt[k], (k, np.asarray(v).dtype, np.asarray(v).shape, dt[k])
+        np.testing.assert_array_equal(counts, z["d_counts"][t])
+        np.testing.assert_array_equal(actions, z["d_actions"][t])
+        np.testing.assert_allclose(Qs, z["d_Qs"][t], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(V, z["d_V"][t], rtol=1e-9)
+        assert int(action) == int(z["d_action"][t])
+        np.testing.assert_allclose(stable_normalizer(counts, 1.0), z["d_pi"][t], rtol=1e-12)
+        obs, r, done, _ = env.step(int(action))
+        ag.mcts_forward(int(action), obs)
+
+
+def test_terminal_root_is_a_value_error(backend):
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64], nonlinearity="relu", num_actions=2)
+    m = MCTSDiscrete(model=pol, num_actions=2, n_rollouts=4, c_uct=1.5, gamma=1, epsilon=0.0, V_target_policy="off_policy", device="cpu",
+                     root_state=None)
+    with pytest.raises(ValueError):
+        m.search(CartPoleEnv(state=[3.0, 0, 0, 0]))
+
+
+def test_batched_search_over_a_list_of_envs(backend):
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    m = MCTSContinuous(model=pol, n_rollouts=30, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0, V_target_policy="off_policy",
+                       device="cpu", root_state=None)
+    envs = [PendulumEnv(state=[0.1 * i, 0.05 * i]) for i in range(5)]
+    before = [e.azg_state().copy() for e in envs]
+    m.search(envs)
+    rows = m.return_results("max_visit")
+    assert len(rows) == 5
+    for (s, a, c, q, v), b, e in zip(rows, before, envs):
+        assert c.sum() == 30 and q.shape == (len(c), 1) and s.shape == (3,)
+        np.testing.assert_array_equal(e.azg_state(), b)   # Env must not be mutated (the reference deep-copies it)
+
+
+def test_weights_are_resynced_after_an_optimiser_step(backend):
+    ag = _cont_agent()
+    env = PendulumEnv(state=[0.3, 0.1])
+    ag.reset_mcts(env._get_obs())
+    a0, s, actions, counts, Qs, V = ag.act(env)
+    v0 = ag.mcts._batched.engine.root_eval()[0][0]
+    buf = ReplayBuffer(100, 4)
+    for _ in range(4):
+        buf.store((s, np.resize(actions, 5).astype(np.float32), np.resize(counts, 5).astype(np.float32), Qs[:1], np.float64(V)))
+    info = ag.train(buf)
+    assert set(info) == {"loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss"}
+    ag.act(env)
+    v1 = ag.mcts._batched.engine.root_eval()[0][0]
+    with torch.no_grad():
+        expect = float(ag.nn.predict_V(torch.from_numpy(env._get_obs()).float()[None])[0, 0])
+    assert v0 != v1 and abs(v1 - expect) < 1e-5
+
+
+def test_training_step_matches_reference_losses():
+    z = np.load(os.path.join(P.GOLDEN, "t5_training.npz"))
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    load_blob(pol, O.make_weights(21, 3, [64, 64], 2))
+    lp, ent, vh = pol.get_train_data(torch.from_numpy(z["c_states"]), torch.from_numpy(z["c_actions"]))
+    np.testing.assert_allclose(lp.detach().numpy(), z["c_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ent.detach().numpy(), z["c_entropy"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(vh.detach().numpy(), z["c_V_hat"], rtol=1e-5, atol=1e-5)
+    d = A0CLoss(tau=0.1, policy_coeff=0.1, alpha=0.5, value_coeff=1, reduction="mean")(
+        log_probs=lp, counts=torch.from_numpy(z["c_counts"]), entropy=ent, V=torch.from_numpy(z["c_V"]), V_hat=vh)
+    np.testing.assert_allclose([float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss")], z["c_a0c"], rtol=1e-5)
+    lt = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0, device="cpu")
+    d = lt(log_probs=lp, counts=torch.from_numpy(z["c_counts"]), entropy=ent, V=torch.from_numpy(z["c_V"]), V_hat=vh)
+    got = [float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss")] + [float(lt.alpha)]
+    np.testing.assert_allclose(got, z["c_a0c_tuned"], rtol=1e-5)
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=2)
+    load_blob(pol, O.make_weights(22, 4, [64, 64], 2))
+    lp, ent, vh = pol.get_train_data(torch.from_numpy(z["d_states"]), torch.from_numpy(z["d_actions"]))
+    np.testing.assert_allclose(lp.detach().numpy(), z["d_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ent.detach().numpy(), z["d_entropy"], rtol=1e-5, atol=1e-5)
+    dist, vh2 = pol(torch.from_numpy(z["d_states"]))
+    d = AlphaZeroLoss(1.0, 0.5, "mean")(dist.logits if False else pol._get_dist_params(torch.from_numpy(z["d_states"]))[0],
+                                        torch.softmax(torch.from_numpy(z["d_counts"]), dim=-1), vh2, torch.from_numpy(z["d_V"]))
+    np.testing.assert_allclose([float(d[k]) for k in ("loss", "policy_loss", "value_loss")], z["d_az"], rtol=1e-5)
+
+
+def test_replay_buffer_fifo_and_last_batch_rule():
+    buf = ReplayBuffer(max_size=5, batch_size=2)
+    for i in range(7):
+        buf.store((np.full(3, i), np.full(2, i), np.full(2, i), np.full(2, i), np.float64(i)))
+    assert len(buf) == 5 and sorted(int(e[4]) for e in buf.experience) == [2, 3, 4, 5, 6]   # 0 and 1 were overwritten
+    np.random.seed(0)
+    buf.reshuffle()
+    sizes = [b[0].shape[0] for b in buf]
+    assert sizes == [2, 3]   # the last batch absorbs the remainder (buffers.py:108-123)
+
+
+def test_helpers_and_config():
+    np.testing.assert_allclose(stable_normalizer(np.array([1, 3]), 1.0), [0.25, 0.75])
+    np.testing.assert_allclose(stable_normalizer(np.array([2.0, 4.0]), 2.0), [0.2, 0.8])
+    assert argmax(np.array([0.0, 2.0, 1.0])) == 1
+    assert config.resolve("alphazero.search.mcts.MCTSContinuous") is MCTSContinuous
+    opt = config.instantiate(dict(_target_="torch.optim.RMSprop", lr=0.01), params=[torch.nn.Parameter(torch.zeros(1))])
+    assert isinstance(opt, torch.optim.RMSprop)
+
+
+def test_reference_policy_objects_are_accepted_by_policy_blob():
+    """The engine reads trunk / value_head / dist_head: duck-typing that the reference's own policy classes satisfy."""
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[32, 48], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    desc, blob = _capi.policy_blob(pol)
+    assert desc.n_hidden == 2 and list(desc.hidden)[:2] == [32, 48] and desc.n_dist == 2 and desc.activation == _capi.ACT["elu"]
+    assert blob.size == 3 * 32 + 32 + 32 * 48 + 48 + 48 + 1 + 2 * 48 + 2

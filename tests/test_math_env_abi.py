@@ -1,0 +1,106 @@
+"""CPU: deterministic math header, env restatements, Philox known answers, and the C-ABI surface of the HIP library."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+
+import oracle_lib as O
+from alphazero_gym_amd.envs import CartPoleEnv, PendulumEnv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_philox4x32_10_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    lib = O.lib()
+    lib.azo_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    lib.azo_philox.restype = None
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        out = (C.c_uint32 * 4)()
+        lib.azo_philox(*ctr, *key, out)
+        assert tuple(out) == want
+
+
+def test_math_accuracy_against_libm():
+    x = np.linspace(-20, 5, 100001); xf = x.astype(np.float32).astype(np.float64)
+    assert np.max(np.abs(O.math_eval(0, x) / np.exp(xf) - 1)) < 2e-7
+    x = np.linspace(-20, 20, 100001); xf = x.astype(np.float32).astype(np.float64)
+    ref = np.expm1(xf)
+    assert np.max(np.abs(O.math_eval(1, x) - ref) / np.maximum(np.abs(ref), 1e-30)) < 3e-7
+    assert O.math_eval(1, np.array([0.0]))[0] == 0.0 and not np.signbit(O.math_eval(1, np.array([-0.0]))[0])
+    x = np.linspace(-12, 12, 100001); xf = x.astype(np.float32).astype(np.float64)
+    assert np.max(np.abs(O.math_eval(2, x) - np.tanh(xf))) < 2e-7
+    x = np.linspace(1e-8, 1, 100001)[:-1]; xf = x.astype(np.float32).astype(np.float64)
+    assert np.max(np.abs(O.math_eval(3, x) - np.log(xf)) / np.maximum(np.abs(np.log(xf)), 1e-3)) < 1e-6
+    assert np.max(np.abs(O.math_eval(4, x) - np.cos(2 * np.pi * xf))) < 2e-7
+    x = np.linspace(-100, 100, 200001)
+    assert np.max(np.abs(O.math_eval(5, x) - np.sin(x))) < 3e-16 and np.max(np.abs(O.math_eval(6, x) - np.cos(x))) < 3e-16
+    np.testing.assert_array_equal(O.math_eval(7, x), x % (2 * np.pi))   # Python float % is exact; so is azg_pymod
+    n = O.math_eval(8, np.arange(200000))
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
+
+
+def test_pendulum_c_env_matches_numpy_env():
+    rng = np.random.Generator(np.random.PCG64(3))
+    for version, env_id in ((0, 1), (1, 2)):
+        for _ in range(300):
+            th, thd = rng.uniform(-40, 40), rng.uniform(-8, 8)
+            u = np.float32(rng.uniform(-3, 3))
+            e = PendulumEnv(state=[th, thd], version=version)
+            obs, r, done, _ = e.step(np.array([[u]], dtype=np.float32))
+            nxt, rc, dc, obsc = O.env_step(env_id, [th, thd], u)
+            np.testing.assert_allclose(nxt, e.state, rtol=0, atol=1e-13)
+            assert abs(rc - float(r[0])) < 1e-13 and dc is False and done is False
+            np.testing.assert_allclose(obsc, obs.astype(np.float32), atol=1e-7)
+
+
+def test_cartpole_c_env_matches_numpy_env():
+    rng = np.random.Generator(np.random.PCG64(4))
+    n_done = 0
+    for _ in range(400):
+        s = rng.uniform(-1, 1, 4) * np.array([2.6, 3.0, 0.23, 3.0])
+        a = int(rng.integers(0, 2))
+        e = CartPoleEnv(state=s)
+        obs, r, done, _ = e.step(a)
+        nxt, rc, dc, obsc = O.env_step(0, s, a)
+        np.testing.assert_allclose(nxt, e.state, rtol=0, atol=1e-13)
+        assert rc == 1.0 == r and dc == done
+        np.testing.assert_array_equal(obsc, obs)
+        n_done += done
+    assert 0 < n_done < 400
+
+
+def test_hip_library_exports_every_symbol_of_the_header():
+    """The drop-in boundary: every entry point declared in include/azgym.h must be exported by libazgym_hip.so
+    (loading needs no GPU; no compute is called)."""
+    hdr = open(os.path.join(ROOT, "include", "azgym.h")).read()
+    names = sorted(set(re.findall(r"\b(azg_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    path = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "libazgym_hip.so")
+    assert os.path.exists(path), "build it first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = C.CDLL(path)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.azg_abi_version() == 1
+    olib = O.lib()
+    for n in names:
+        if n in ("azg_math_selftest",):
+            continue
+        assert hasattr(olib, "azo_" + n[4:]), n
+
+
+def test_product_package_never_touches_the_oracle():
+    """Parity claims are void if the product path can route through the oracle: no module of the package may name it."""
+    pkg = os.path.join(ROOT, "alphazero_gym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in src and "libazg_oracle" not in src and "azo_" not in src.replace('prefix ``azo_``', ""), f

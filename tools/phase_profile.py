@@ -33,7 +33,7 @@ def main():
     e.sync()
     print("kernel ms", e.last_search_ms())
     rows = (B + 15) // 16 * 4
-    buf = np.zeros((rows, 8), np.uint64)
+    buf = np.zeros((rows, 16), np.uint64)
     lib = _native.lib()
     lib.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
     n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows)
@@ -44,7 +44,8 @@ def main():
         v = buf[:, i].astype(np.float64)
         print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
     print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
-    for i, nm in zip(range(4, 8), ["  mlp: layer0 + barrier", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  mlp: hidden barrier"]):
+    for i, nm in zip(range(4, 11), ["  mlp: layer0 + barrier", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  mlp: hidden barrier",
+                                     "  A: finish leaf", "  B: descent", "  B: env step + create"]):
         v = buf[:, i].astype(np.float64)
         print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  (register-weight layers only)")
 
