@@ -26,6 +26,24 @@ FLOP_PER_SIM = 2 * (3 * 256 + 256 * 256 + 256 * 3)   # 134 144 FLOP p
 PEAK_TFLOPS = 157.3                                    # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_summary.csv; FETCH_SIZE and WRITE_SIZE are collected in separate passes, in KiB; gfx950 reports half
+    of the bytes of wide coalesced reads, so the read side is doubled as the microarch guide prescribes -- an upper bound
+    for this kernel's narrow reads).  None when no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None
+    vals = {}
+    for r in csv.DictReader(open(files[-1])):
+        vals[r["counter"]] = float(r["mean_per_launch"])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(seconds_target=15.0):
     """The C oracle (a scalar port of the reference's per-tree algorithm) on this box's host cores, OpenMP over trees,
     on a bounded sample of the same workload."""
@@ -118,15 +136,17 @@ def main():
         kms = float(np.mean(kernel_ms))
         achieved = B * N_SIMS * FLOP_PER_SIM / (kms * 1e-3) / 1e12
         out = {
-            "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200", "value": sims / elapsed, "unit": "sims/s",
+            "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 MLP (MFMA) + f64 tree statistics",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Pendulum-v1 A0C, {B} trees/GPU x {N_SIMS} sims, 2x256 ELU policy/value MLP, c_uct=0.05 c_pw=1 kappa=0.5",
                        "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": f"{world} independent shards (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": None, "kernel": "search_kernel<PENDULUM,256,1>", "kernel_ms": kms,
-                         "note": "one launch = whole search; algorithmic FLOP = trees x sims x 134144; tree walk is latency-bound (see DESIGN.md)"},
+                         "traffic": profiled_traffic(), "kernel": "search_kernel<PENDULUM_V1,256,1,true>", "kernel_ms": kms,
+                         "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
+                                 "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
+                                 "the committed rocprofv3 PMC passes (profiles/)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
