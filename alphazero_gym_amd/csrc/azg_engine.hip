@@ -174,10 +174,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // azg_expm1f on four values at once: the same operations in the same order per component (bit-identical), written
 // component-parallel so that the four dependent fma chains interleave (and pack into v_pk_fma_f32)
-__device__ __forceinline__ f32x4 expm1f4(f32x4 x) {
-    const f32x4 lo = {-87.0f, -87.0f, -87.0f, -87.0f}, hi = {88.0f, 88.0f, 88.0f, 88.0f};
-    i32x4 mlo = x < lo, mhi = x > hi;
-    f32x4 xc = (f32x4)((((i32x4)lo) & mlo) | ((((i32x4)hi) & mhi) | (((i32x4)x) & ~(mlo | mhi))));
+__device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 x) {
+    // x <= 0 here, so only the lower clamp of azg_expm1f can trigger
+    const f32x4 lo = {-87.0f, -87.0f, -87.0f, -87.0f};
+    f32x4 xc = __builtin_elementwise_max(x, lo);
     const f32x4 magic = {12582912.0f, 12582912.0f, 12582912.0f, 12582912.0f};
     const f32x4 l2e = {1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f};
     const f32x4 ln2h = {0.693145751953125f, 0.693145751953125f, 0.693145751953125f, 0.693145751953125f};
@@ -203,14 +203,14 @@ __device__ __forceinline__ f32x4 expm1f4(f32x4 x) {
     return __builtin_elementwise_fma(sc, em1, sc - one);
 }
 
-// ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit for bit
+// ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(+-0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit
+// for bit (the sign of a zero that v_max/v_min may pick differently from the host's select vanishes in the sum)
 __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    i32x4 m = v > zero;
-    f32x4 pos = (f32x4)(((i32x4)v) & m);
+    f32x4 pos = __builtin_elementwise_max(v, zero);
     if (act == AZG_ACT_ELU) {
-        f32x4 neg = (f32x4)(((i32x4)v) & ~m);
-        return pos + expm1f4(neg);
+        f32x4 neg = __builtin_elementwise_min(v, zero);
+        return pos + expm1f4_nonpos(neg);
     }
     return pos;
 }
@@ -372,21 +372,33 @@ __device__ __forceinline__ double dpp_f64(double v) {
 #define DPP_ROW_ROR4 0x124
 #define DPP_ROW_ROR8 0x128
 
-// lane index (0..15) of the maximum over the row, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
-__device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
+// maximum of u over the row (invalid lanes excluded)
+__device__ __forceinline__ double rowmax16(double u, bool valid) {
     double m = valid ? u : -__builtin_huge_val();
     double o;
     o = dpp_f64<DPP_QUAD_XOR1>(m); m = o > m ? o : m;
     o = dpp_f64<DPP_QUAD_XOR2>(m); m = o > m ? o : m;
     o = dpp_f64<DPP_ROW_ROR4>(m); m = o > m ? o : m;
     o = dpp_f64<DPP_ROW_ROR8>(m); m = o > m ? o : m;
-    int c = (valid && u == m) ? sub : 99;
+    return m;
+}
+__device__ __forceinline__ int rowmin16(int c) {
     int t;
     t = dpp_i32<DPP_QUAD_XOR1>(c); c = t < c ? t : c;
     t = dpp_i32<DPP_QUAD_XOR2>(c); c = t < c ? t : c;
     t = dpp_i32<DPP_ROW_ROR4>(c); c = t < c ? t : c;
     t = dpp_i32<DPP_ROW_ROR8>(c); c = t < c ? t : c;
     return c;
+}
+// lane index (0..15) of the maximum over the row, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
+__device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
+    double m = rowmax16(u, valid);
+    return rowmin16((valid && u == m) ? sub : 99);
+}
+// same, but returns the payload (< 65536) of the winning lane: no second cross-lane round trip
+__device__ __forceinline__ int argmax16_payload(double u, bool valid, int sub, int payload) {
+    double m = rowmax16(u, valid);
+    return rowmin16((valid && u == m) ? ((sub << 16) | payload) : 0x7fffffff) & 0xffff;
 }
 
 // storage of the hot part of one tree: LDS (RecS, 8-bit ids) or global memory (RecL, 16-bit ids)
@@ -411,16 +423,13 @@ __device__ __forceinline__ Rec make_edge(double Q, int parent) {
 __device__ __forceinline__ void clear_pad(RecS&) {}
 __device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
 
-// MCTS.backprop (mcts.py:260-267) for one tree by its 16 lanes: the path is collected 16 levels at a time (lane d = d-th
-// record from the leaf), rewards / W are fetched in parallel, the discounted return is chained serially (its rounding
-// order is part of the contract), then every lane updates its own record.
+// MCTS.backprop (mcts.py:260-267), generic part: walks parent links from record j to the root, 16 levels at a time
+// (lane d = d-th record), fetches rewards / W in parallel, chains the discounted return serially (its rounding order
+// is part of the contract), then every lane updates its own record.
 template <bool CONT, bool TLDS>
-__device__ __forceinline__ void backup(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int leaf, float V, int sub,
-                                       float gamma_f, double gamma) {
+__device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int j, float V, int sub,
+                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv) {
     typedef typename TreeStore<TLDS>::Rec Rec;
-    int j = leaf;
-    bool firstlvl = true, at_leaf = true;
-    double Rv = 0.0;
     while (true) {
         int mine = 0, cnt = 0, jj = j;
         bool hit_root = false;
@@ -467,6 +476,43 @@ __device__ __forceinline__ void backup(const TreeStore<TLDS>& ts, const Cold* co
         if (hit_root) break;
         j = jj;
         at_leaf = false;
+    }
+}
+
+// Backup of a trace whose path the descent left in the lanes: slot (depth & 15) holds the record id, its reward and W
+// (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
+template <bool CONT, bool TLDS>
+__device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
+                                            double gamma, int D, int my_depth, int pid, double pr, double pW) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    const int n0 = D < 16 ? D : 16;
+    double Rv = 0.0, myR = 0.0;
+#pragma unroll 1
+    for (int d = 0; d < n0; ++d) {
+        const int src = (D - d) & 15;
+        double rd = __shfl(pr, src, 16);
+        double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * Rv;
+        Rv = rd + gR;
+        if (sub == src) myR = Rv;
+    }
+    const bool valid = my_depth >= 0 && my_depth > D - 16;
+    int par = 0;
+    if (valid) {
+        Rec rec = ts.hot[pid];
+        par = rec.parent;
+        if (my_depth >= 1) {
+            int en = (int)rec.edge_n + 1;
+            double Wn = pW + myR;
+            rec.Q = Wn / (double)en;
+            rec.edge_n = (decltype(rec.edge_n))en;
+            edge_W[pid] = Wn;
+        }
+        if (my_depth < D) rec.node_n = (decltype(rec.node_n))(rec.node_n + 1);
+        ts.hot[pid] = rec;
+    }
+    if (D >= 16) {
+        int j = __shfl(par, (D - 15) & 15, 16);   // parent of the shallowest record handled above
+        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv);
     }
 }
 
@@ -550,6 +596,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     unsigned eps_draws = 0;
     int leaf = 0;
     bool need_eval = live;
+    // the current trace's path, one record per lane (slot = depth & 15): id, reward, W -- consumed by backup_path
+    int path_D = 0, my_depth = -1, pid = 0;
+    double pr = 0.0, pW = 0.0;
     // progressive-widening noise: lane `sub` holds the N(0,1) draw for record kbase + sub
     int kbase = 1;
     float eps_c = 0.0f;
@@ -647,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             STAMP_ADD(8, t_c, t_c2);    // finish leaf (before backup)
             if (sim >= 0) {
                 if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
-                backup<CONT, TLDS>(ts, cold, edge_W, leaf, V, sub, P.gamma_f, P.gamma);
+                backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, path_D, my_depth, pid, pr, pW);
             }
         }
         if (sim == P.n_sims - 1) break;
@@ -664,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             int p = 0;
             Rec hp = ts.hot[0];
             Cold cp = cold[0];   // cold part of the current node, prefetched one level ahead
+            path_D = 0; my_depth = sub == 0 ? 0 : -1; pid = 0; pr = 0.0; pW = 0.0;
             while (true) {
                 const int K = hp.n_child;
                 int chosen;
@@ -697,15 +747,13 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     }
                     const double sq = s_sqrt[hp.node_n];
                     int win_c = 0;
-                    double win_u = 0.0;
-                    bool have = false;
-                    for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
-                        const int i = base + sub;
-                        const bool valid = i < K;
+                    if (K <= 16) {
+                        // the common case: all children fit one 16-lane row
+                        const bool valid = sub < K;
                         int c = 0;
                         double U = 0.0;
                         if (valid) {
-                            c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
+                            c = CONT ? (int)ts.child[p * P.Kp + sub] : (int)hp.first + sub;
                             Rec h = ts.hot[c];
                             double ratio = sq / (double)((int)h.edge_n + 1);
                             if (CONT) {
@@ -715,21 +763,48 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                                 U = h.Q + (double)pc * ratio;
                             }
                         }
-                        int w;
-                        if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
-                        else w = argmax16(U, valid, sub);
-                        if (w >= 0) {
-                            int wc = __shfl(c, w, 16);
-                            double wu = __shfl(U, w, 16);
-                            if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
+                        if (pick >= 0) win_c = __shfl(c, pick, 16);
+                        else win_c = argmax16_payload(U, valid, sub, c);
+                    } else {
+                        double win_u = 0.0;
+                        bool have = false;
+                        for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
+                            const int i = base + sub;
+                            const bool valid = i < K;
+                            int c = 0;
+                            double U = 0.0;
+                            if (valid) {
+                                c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
+                                Rec h = ts.hot[c];
+                                double ratio = sq / (double)((int)h.edge_n + 1);
+                                if (CONT) {
+                                    U = h.Q + P.c_uct * ratio;
+                                } else {
+                                    float pc = ts.prior[c] * P.c_uct_f;
+                                    U = h.Q + (double)pc * ratio;
+                                }
+                            }
+                            int w;
+                            if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
+                            else w = argmax16(U, valid, sub);
+                            if (w >= 0) {
+                                int wc = __shfl(c, w, 16);
+                                double wu = __shfl(U, w, 16);
+                                if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
+                            }
                         }
                     }
                     chosen = win_c;
                     hc = ts.hot[chosen];
                 }
+                path_D += 1;
                 if (hc.flags & FLAG_EXPANDED) {
                     p = chosen;
                     hp = hc;
+                    if (sub == (path_D & 15)) {   // only the slot's lane fetches the level's reward and W (used by backup_path)
+                        my_depth = path_D; pid = chosen;
+                        pr = cold[chosen].r; pW = edge_W[chosen];
+                    }
                     if (hc.flags & FLAG_TERMINAL) { leaf = p; break; }
                     cp = cold[p];
                     continue;
@@ -757,6 +832,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     cold[chosen] = c;
                     ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
                 }
+                if (sub == (path_D & 15)) { my_depth = path_D; pid = chosen; pr = r; pW = 0.0; }
                 leaf = chosen;
                 need_eval = !done;
                 if (sub < 4) s_obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
