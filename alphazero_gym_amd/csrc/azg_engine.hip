@@ -704,6 +704,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         STAMP(t_d);
 
         // ================= tree phase B: next trace: select down, step the env, expand =================
+        // The descent loop contains only UCT levels, so the four trees of a wave run the same code and differ only in
+        // trip count; widening and expansion happen once, after the loop, for all four trees together.
         need_eval = false;
         if (live) {
             if (CONT && nrec >= kbase + 16) {
@@ -714,104 +716,112 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             Rec hp = ts.hot[0];
             Cold cp = cold[0];   // cold part of the current node, prefetched one level ahead
             path_D = 0; my_depth = sub == 0 ? 0 : -1; pid = 0; pr = 0.0; pW = 0.0;
+            int chosen = 0;
+            bool widen = false, hit_terminal = false;
             while (true) {
                 const int K = hp.n_child;
-                int chosen;
-                float cact = 0.0f;
-                bool widen = false;
                 if (CONT) {
                     int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
                     widen = s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
+                    if (widen) break;
                 }
-                Rec hc;
-                if (widen) {
-                    // MCTSContinuous.add_pw_action (mcts.py:625-654)
-                    chosen = nrec++;
-                    float eps = __shfl(eps_c, chosen - kbase, 16);
-                    cact = P.bound_f * azg_tanhf(cp.mu + cp.sg * eps);
-                    hc = make_edge<Rec>((double)cp.V, p);
-                    clear_pad(hc);
-                    if (sub == 0) {
-                        ts.hot[chosen] = hc;
-                        edge_W[chosen] = 0.0;
-                        action[chosen] = cact;
-                        ts.child[p * P.Kp + K] = (Id)chosen;
-                        ts.hot[p].n_child = (decltype(hp.n_child))(K + 1);
+                STAMP(t_l0);
+                int pick = -1;
+                if (P.epsilon != 0.0) {
+                    // MCTS.epsilon_greedy (mcts.py:190-195)
+                    azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, eps_draws++, AZG_STREAM_EPS);
+                    if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
+                }
+                const double sq = s_sqrt[hp.node_n];
+                int win_c = 0;
+                if (K <= 16) {
+                    // the common case: all children fit one 16-lane row
+                    const bool valid = sub < K;
+                    int c = 0;
+                    double U = 0.0;
+                    if (valid) {
+                        c = CONT ? (int)ts.child[p * P.Kp + sub] : (int)hp.first + sub;
+                        Rec h = ts.hot[c];
+                        double ratio = sq / (double)((int)h.edge_n + 1);
+                        if (CONT) {
+                            U = h.Q + P.c_uct * ratio;
+                        } else {
+                            float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+                            U = h.Q + (double)pc * ratio;
+                        }
                     }
+                    if (pick >= 0) win_c = __shfl(c, pick, 16);
+                    else win_c = argmax16_payload(U, valid, sub, c);
                 } else {
-                    int pick = -1;
-                    if (P.epsilon != 0.0) {
-                        // MCTS.epsilon_greedy (mcts.py:190-195)
-                        azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, eps_draws++, AZG_STREAM_EPS);
-                        if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
-                    }
-                    const double sq = s_sqrt[hp.node_n];
-                    int win_c = 0;
-                    if (K <= 16) {
-                        // the common case: all children fit one 16-lane row
-                        const bool valid = sub < K;
+                    double win_u = 0.0;
+                    bool have = false;
+                    for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
+                        const int i = base + sub;
+                        const bool valid = i < K;
                         int c = 0;
                         double U = 0.0;
                         if (valid) {
-                            c = CONT ? (int)ts.child[p * P.Kp + sub] : (int)hp.first + sub;
+                            c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
                             Rec h = ts.hot[c];
                             double ratio = sq / (double)((int)h.edge_n + 1);
                             if (CONT) {
                                 U = h.Q + P.c_uct * ratio;
                             } else {
-                                float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+                                float pc = ts.prior[c] * P.c_uct_f;
                                 U = h.Q + (double)pc * ratio;
                             }
                         }
-                        if (pick >= 0) win_c = __shfl(c, pick, 16);
-                        else win_c = argmax16_payload(U, valid, sub, c);
-                    } else {
-                        double win_u = 0.0;
-                        bool have = false;
-                        for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
-                            const int i = base + sub;
-                            const bool valid = i < K;
-                            int c = 0;
-                            double U = 0.0;
-                            if (valid) {
-                                c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
-                                Rec h = ts.hot[c];
-                                double ratio = sq / (double)((int)h.edge_n + 1);
-                                if (CONT) {
-                                    U = h.Q + P.c_uct * ratio;
-                                } else {
-                                    float pc = ts.prior[c] * P.c_uct_f;
-                                    U = h.Q + (double)pc * ratio;
-                                }
-                            }
-                            int w;
-                            if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
-                            else w = argmax16(U, valid, sub);
-                            if (w >= 0) {
-                                int wc = __shfl(c, w, 16);
-                                double wu = __shfl(U, w, 16);
-                                if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
-                            }
+                        int w;
+                        if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
+                        else w = argmax16(U, valid, sub);
+                        if (w >= 0) {
+                            int wc = __shfl(c, w, 16);
+                            double wu = __shfl(U, w, 16);
+                            if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
                         }
                     }
-                    chosen = win_c;
-                    hc = ts.hot[chosen];
                 }
+                chosen = win_c;
+                Rec hc = ts.hot[chosen];
+                STAMP(t_l1);
+#ifdef AZG_STAMPS
+                st_acc[11] += t_l1 - t_l0; st_acc[12] += 1;
+#endif
+                if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it
                 path_D += 1;
-                if (hc.flags & FLAG_EXPANDED) {
-                    p = chosen;
-                    hp = hc;
-                    if (sub == (path_D & 15)) {   // only the slot's lane fetches the level's reward and W (used by backup_path)
-                        my_depth = path_D; pid = chosen;
-                        pr = cold[chosen].r; pW = edge_W[chosen];
+                p = chosen;
+                hp = hc;
+                if (sub == (path_D & 15)) {   // only the slot's lane fetches the level's reward and W (used by backup_path)
+                    my_depth = path_D; pid = chosen;
+                    pr = cold[chosen].r; pW = edge_W[chosen];
+                }
+                if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
+                cp = cold[p];
+            }
+            STAMP(t_x);
+            STAMP_ADD(9, t_d, t_x);    // descent until the expansion point
+            if (hit_terminal) {
+                leaf = p;
+            } else {
+                float cact = 0.0f;
+                if (widen) {
+                    // MCTSContinuous.add_pw_action (mcts.py:625-654)
+                    const int K = hp.n_child;
+                    chosen = nrec++;
+                    float eps = __shfl(eps_c, chosen - kbase, 16);
+                    cact = P.bound_f * azg_tanhf(cp.mu + cp.sg * eps);
+                    if (sub == 0) {
+                        Rec h = make_edge<Rec>((double)cp.V, p);
+                        clear_pad(h);
+                        ts.hot[chosen] = h;
+                        edge_W[chosen] = 0.0;
+                        action[chosen] = cact;
+                        ts.child[p * P.Kp + K] = (Id)chosen;
+                        ts.hot[p].n_child = (decltype(hp.n_child))(K + 1);
                     }
-                    if (hc.flags & FLAG_TERMINAL) { leaf = p; break; }
-                    cp = cold[p];
-                    continue;
                 }
                 // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
-                STAMP(t_x);
-                STAMP_ADD(9, t_d, t_x);    // descent until the expansion point
+                path_D += 1;
                 double ns[S], r, sn;
                 int done;
                 if (CONT) {
@@ -836,10 +846,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                 leaf = chosen;
                 need_eval = !done;
                 if (sub < 4) s_obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
-                STAMP(t_y);
-                STAMP_ADD(10, t_x, t_y);   // env step + node creation
-                break;
             }
+            STAMP(t_y);
+            STAMP_ADD(10, t_x, t_y);   // widen + env step + node creation
         }
         __threadfence_block();
         STAMP(t_e);

@@ -45,9 +45,11 @@ def main():
         print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
     print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
     for i, nm in zip(range(4, 11), ["  mlp: layer0 + barrier", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  mlp: hidden barrier",
-                                     "  A: finish leaf", "  B: descent", "  B: env step + create"]):
+                                     "  A: finish leaf", "  B: descent", "  B: widen+env step+create"]):
         v = buf[:, i].astype(np.float64)
-        print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  (register-weight layers only)")
+        print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
+    b = buf.astype(np.float64)
+    print(f"  B: UCT level   {b[:, 11].sum() / max(b[:, 12].sum(), 1):8.0f} cycles each, {b[:, 12].mean() / (n_sims + 1):.2f} per step (wave-level: max over 4 trees)")
 
 
 if __name__ == "__main__":
