@@ -157,3 +157,75 @@ def make_game(game: str):
     if name == "pendulum":
         return PendulumEnv(version=0 if game.endswith("v0") else 1)
     raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole and Pendulum only")
+
+
+class VecPendulum:
+    """B Pendulum environments stepped together (numpy float64, same operation order as PendulumEnv.step)."""
+
+    def __init__(self, n: int, version: int = 1, seed: int = 0):
+        self.n, self.version = n, version
+        self.azg_env_id = ENV_PENDULUM_V1 if version == 1 else ENV_PENDULUM_V0
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros((n, 2))
+        self.reset(np.ones(n, bool))
+
+    def reset(self, mask):
+        k = int(mask.sum())
+        if k:
+            self.state[mask] = self.rng.uniform(low=[-np.pi, -1.0], high=[np.pi, 1.0], size=(k, 2))
+
+    def obs(self):
+        th, thd = self.state[:, 0], self.state[:, 1]
+        return np.stack([np.cos(th), np.sin(th), thd], 1)
+
+    def step(self, u):
+        th, thd = self.state[:, 0], self.state[:, 1]
+        u = np.clip(np.asarray(u, np.float32).reshape(-1), np.float32(-2.0), np.float32(2.0)).astype(np.float64)
+        an = ((th + np.pi) % (2.0 * np.pi)) - np.pi
+        costs = (an * an + 0.1 * (thd * thd)) + 0.001 * (u * u)
+        if self.version == 1:
+            nthd = np.clip(thd + (15.0 * np.sin(th) + 3.0 * u) * 0.05, -8.0, 8.0)
+            nth = th + nthd * 0.05
+        else:
+            nthd = thd + (-15.0 * np.sin(th + np.pi) + 3.0 * u) * 0.05
+            nth = th + nthd * 0.05
+            nthd = np.clip(nthd, -8.0, 8.0)
+        self.state = np.stack([nth, nthd], 1)
+        return -costs, np.zeros(self.n, bool)
+
+
+class VecCartPole:
+    """B CartPole environments stepped together (numpy float64, same operation order as CartPoleEnv.step)."""
+
+    azg_env_id = ENV_CARTPOLE
+
+    def __init__(self, n: int, seed: int = 0):
+        self.n = n
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros((n, 4))
+        self.reset(np.ones(n, bool))
+
+    def reset(self, mask):
+        k = int(mask.sum())
+        if k:
+            self.state[mask] = self.rng.uniform(low=-0.05, high=0.05, size=(k, 4))
+
+    def obs(self):
+        return self.state.astype(np.float32)
+
+    def step(self, action):
+        x, x_dot, theta, theta_dot = self.state.T
+        force = np.where(np.asarray(action).reshape(-1) == 1, 10.0, -10.0)
+        costheta, sintheta = np.cos(theta), np.sin(theta)
+        total_mass, pml = CartPoleEnv.total_mass, CartPoleEnv.polemass_length
+        temp = (force + (pml * (theta_dot * theta_dot)) * sintheta) / total_mass
+        thetaacc = (9.8 * sintheta - costheta * temp) / (0.5 * (4.0 / 3.0 - (0.1 * (costheta * costheta)) / total_mass))
+        xacc = temp - ((pml * thetaacc) * costheta) / total_mass
+        x = x + 0.02 * x_dot
+        x_dot = x_dot + 0.02 * xacc
+        theta = theta + 0.02 * theta_dot
+        theta_dot = theta_dot + 0.02 * thetaacc
+        self.state = np.stack([x, x_dot, theta, theta_dot], 1)
+        thr = CartPoleEnv.theta_threshold_radians
+        done = (x < -2.4) | (x > 2.4) | (theta < -thr) | (theta > thr)
+        return np.ones(self.n), done

@@ -1,0 +1,57 @@
+"""The training drivers (reference loop shape) and the batched self-play loop, on the oracle test double (CPU) and the
+HIP engine (gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from alphazero_gym_amd import distributed as D, run
+from alphazero_gym_amd.network.policies import make_policy
+
+BACKENDS = ["oracle_double", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request, monkeypatch):
+    from alphazero_gym_amd import _native
+    if request.param == "oracle_double":
+        monkeypatch.setattr(_native, "HipEngine", O.OracleEngine)
+    else:
+        _native.lib()
+    return request.param
+
+
+def test_run_continuous_agent_two_short_episodes(backend):
+    torch.manual_seed(0)
+    logs = []
+    rets = run.run_continuous_agent(dict(num_train_episodes=2, max_episode_length=6, mcts=dict(n_rollouts=10),
+                                         policy=dict(hidden_dimensions=[64, 64]), buffer=dict(max_size=50, batch_size=4)),
+                                    log=lambda info, ep: logs.append(info))
+    assert len(rets) == 2 and all(r < 0 for r in rets)
+    assert {"loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss", "Episode reward"} <= set(logs[0])
+    assert all(np.isfinite(float(v)) for v in logs[-1].values())
+
+
+def test_run_discrete_agent_two_short_episodes(backend):
+    torch.manual_seed(0)
+    rets = run.run_discrete_agent(dict(num_train_episodes=2, max_episode_length=8, mcts=dict(n_rollouts=8),
+                                       policy=dict(hidden_dimensions=[64]), buffer=dict(max_size=50, batch_size=4)))
+    assert len(rets) == 2 and all(1 <= r <= 8 for r in rets)
+
+
+def test_batched_selfplay_rows_and_episode_bookkeeping(backend):
+    torch.manual_seed(0)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    sp = run.BatchedSelfPlay(pol, game="Pendulum-v1", n_games=6, n_rollouts=16, c_uct=0.05, max_episode_length=3)
+    rows = sp.collect(4)
+    K = 4   # ceil(sqrt(16))
+    assert rows.shape == (24, 3 + 3 * K + 1)
+    s, a, c, q, v = D.unpack_replay_rows(rows, 3, K)
+    np.testing.assert_array_equal(c.sum(1), np.full(24, 16.0))
+    np.testing.assert_allclose(np.hypot(s[:, 0], s[:, 1]), 1.0, atol=1e-6)
+    assert len(sp.finished_returns) == 6   # every game hit max_episode_length once in 4 steps
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64], nonlinearity="relu", num_actions=2)
+    sp = run.BatchedSelfPlay(pol, game="CartPole-v1", n_games=5, n_rollouts=12, c_uct=1.5, max_episode_length=50)
+    rows = sp.collect(3)
+    assert rows.shape == (15, 4 + 3 * 2 + 1)
