@@ -522,13 +522,11 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
     typedef typename TreeStore<TLDS>::Id Id;
-    __shared__ f32x4 s_actA[HP / 16 * 64];
-    __shared__ f32x4 s_actB[HP / 16 * 64];
     __shared__ f32x4 s_parts[4 * 64];
     __shared__ float s_obsT[4 * 16];
     __shared__ float s_outs[16 * 16];
     __shared__ float s_bhead[16];
-    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, then (TLDS) the 16 trees' hot records
+    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, two activation buffers, (TLDS) the 16 trees' hot records
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -540,6 +538,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
 
     double* s_sqrt = s_dyn;
     int* s_pw = (int*)(s_dyn + P.tab_n);
+    const size_t act_off = ((size_t)P.tab_n * 8 + (size_t)(P.n_sims + 2) * 4 + 15) / 16 * 16;
+    f32x4* s_actA = (f32x4*)((char*)s_dyn + act_off);
+    f32x4* s_actB = s_actA + HP / 16 * 64;
     for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
     if (tid < 16) s_bhead[tid] = P.bhead[tid];
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     TreeStore<TLDS> ts;
     if (TLDS) {
         // per tree: R records of 16 B, then (continuous) R x Kp child ids or (discrete) R priors
-        size_t off = ((size_t)P.tab_n * 8 + (size_t)(P.n_sims + 2) * 4 + 15) / 16 * 16;
+        size_t off = act_off + (size_t)2 * HP * 64;
         size_t per = (size_t)P.R * 16 + (CONT ? (size_t)P.R * P.Kp : (size_t)P.R * 4);
         per = (per + 15) / 16 * 16;
         char* base = (char*)s_dyn + off + per * tl;
@@ -1022,8 +1023,25 @@ static hipError_t launch_t(azg_engine* e) {
     return hipGetLastError();
 }
 
+// LDS plan of one launch: tables + two activation buffers (+ the 16 trees' hot records when they fit: 8-bit record ids,
+// 16-bit counts, <= 16 children per node, and the 160 KB of a CU)
+static void plan_lds(azg_engine* e) {
+    const int ns = e->cfg.n_sims;
+    const bool cont = e->cfg.mode == AZG_MODE_CONTINUOUS;
+    size_t off = ((size_t)e->tab_n * 8 + (size_t)(ns + 2) * 4 + 15) / 16 * 16 + (size_t)2 * e->HP * 64;
+    size_t per = (size_t)e->R * 16 + (cont ? (size_t)e->R * e->Kp : (size_t)e->R * 4);
+    per = (per + 15) / 16 * 16;
+    const size_t static_lds = 4096 + 1024 + 256 + 64 + 64;   // head partials, outputs, observations, head bias (+ slack)
+    bool fits = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536 && off + per * TREES_PER_WG + static_lds <= 160 * 1024;
+    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
+    if (force && force[0] == '1') fits = false;
+    e->tree_lds = fits ? 1 : 0;
+    e->dyn_lds = fits ? off + per * TREES_PER_WG : off;
+}
+
 template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {
+    plan_lds(e);
     return e->tree_lds ? launch_t<ENV, HP, NREG, true>(e) : launch_t<ENV, HP, NREG, false>(e);
 }
 
@@ -1046,6 +1064,8 @@ static hipError_t dispatch(azg_engine* e) {
         if (NR == 1) return launch<ENV, 256, 1>(e);
         return launch<ENV, 256, 0>(e);
     }
+    if (HP == 512) return launch<ENV, 512, 0>(e);
+    if (HP == 1024) return launch<ENV, 1024, 0>(e);
     return hipErrorInvalidValue;
 }
 
@@ -1109,20 +1129,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->Kp = (e->Kmax + 15) / 16 * 16;
     // sqrt(n+1) table: node visit counts reach n_sims (+ the carried root count in discrete mode, <= 3 n_sims)
     e->tab_n = cfg->mode == AZG_MODE_CONTINUOUS ? ns + 2 : 4 * ns + 4;
-    {
-        // LDS-resident hot records when a tree fits: 8-bit record ids, 16-bit counts, <= 16 children per node
-        size_t off = ((size_t)e->tab_n * 8 + (size_t)(ns + 2) * 4 + 15) / 16 * 16;
-        size_t per = (size_t)e->R * 16 + (cfg->mode == AZG_MODE_CONTINUOUS ? (size_t)e->R * e->Kp : (size_t)e->R * 4);
-        per = (per + 15) / 16 * 16;
-        size_t with_trees = off + per * TREES_PER_WG;
-        // static LDS of the largest kernel (HP = 256): two activation buffers + head partials + small arrays
-        const size_t static_max = 2 * 256 * 64 + 4096 + 1024 + 256 + 64 + 64;
-        bool fits = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536 && with_trees + static_max <= 160 * 1024;
-        const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
-        if (force && force[0] == '1') fits = false;
-        e->tree_lds = fits ? 1 : 0;
-        e->dyn_lds = fits ? with_trees : off;
-    }
+    e->tree_lds = 0;
+    e->dyn_lds = 0;
     if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
 #define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
@@ -1201,8 +1209,8 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     need += (size_t)(1 + d->n_dist) * k + (1 + d->n_dist);
     if (need != n_floats) return fail(e, AZG_E_INVALID, "weight blob size mismatch");
     const int HP = pad64(hmax);
-    if (HP != 64 && HP != 128 && HP != 256)
-        return fail(e, AZG_E_UNSUPPORTED, "hidden width (padded to a multiple of 64) must be one of 64,128,256");
+    if (HP != 64 && HP != 128 && HP != 256 && HP != 512 && HP != 1024)
+        return fail(e, AZG_E_UNSUPPORTED, "hidden width (padded to a multiple of 64) must be one of 64,128,256,512,1024");
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (void* p : e->weight_allocs) (void)hipFree(p);

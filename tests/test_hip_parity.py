@@ -94,6 +94,10 @@ CONFIGS = [
     (0, 0, [128, 128], "relu", 100, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
     (0, 0, [64, 64], "elu", 60, dict(c_uct=20.0, gamma=0.95, epsilon=0.1, num_actions=2, v_target="on_policy")),
     (0, 0, [256, 256], "relu", 80, dict(c_uct=5.0, gamma=0.99, num_actions=2)),
+    # wide MLPs (BASELINE config E is 4x1024): weights streamed from L2, activation buffers up to 128 KB of LDS
+    (2, 1, [512, 512], "elu", 30, dict(c_uct=0.05, gamma=1.0)),
+    (2, 1, [1024, 1024, 1024, 1024], "elu", 12, dict(c_uct=0.05, gamma=1.0)),
+    (0, 0, [512], "relu", 40, dict(c_uct=3.0, gamma=1.0, num_actions=2)),
     # trees too large for LDS residency (> 255 records): global-memory tree storage
     (2, 1, [64, 64], "elu", 300, dict(c_uct=0.05, gamma=1.0)),
     (0, 0, [64, 64], "relu", 200, dict(c_uct=8.0, gamma=0.98, num_actions=2)),
