@@ -235,11 +235,13 @@ struct WRegs {
     f32x4 b0[NTW];
 };
 
-// The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  outs: [16 trees][16 outputs].
-// Activations: act buffers of HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand.
+// The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  Result: parts[4 waves][64 lanes] = every
+// wave's partial head sums (head_output() combines them).  Activations cross waves through the two act buffers
+// (HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in
+// registers until the next layer publishes it, and the last layer's output feeds the head MFMAs directly.
 template <int HP, int NREG>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
-                                            f32x4* parts, float* outs, const float* s_bhead, int wave, int lane
+                                            f32x4* parts, int wave, int lane
 #ifdef AZG_STAMPS
                                             , unsigned long long* st_acc
 #endif
@@ -247,34 +249,32 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
     STAMP(m0);
     constexpr int NTW = HP / 64;   // output tiles per wave
     constexpr int S4 = HP / 16;    // groups of 4 MFMA k-steps over a hidden vector
+    f32x4 h[NTW];                  // this wave's tiles of the latest layer, after the activation
     // layer 0: K = in_dim <= 4 -> one k-step
     {
         float b = obsT[lane];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            int nt = wave * NTW + i;
-            f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0);
-            actA[nt * 64 + lane] = act4(P.act, acc);
-        }
+        for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
     }
-    __syncthreads();
-    STAMP(m1);
-    STAMP_ADD(4, m0, m1);
-    f32x4* in = actA;
-    f32x4* out = actB;
+    f32x4* buf = actA;
+    f32x4* other = actB;
     // hidden->hidden layers held in registers
     if (NREG > 0) {
 #pragma unroll
         for (int l = 0; l < NREG; ++l) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            __syncthreads();
+            STAMP(m1);
             f32x4 acc[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i] = wr.b[l][i];
-            f32x4 bcur = in[lane];
+            f32x4 bcur = buf[lane];
 #pragma unroll
             for (int s4 = 0; s4 < S4; ++s4) {
                 f32x4 bnext = bcur;
-                if (s4 + 1 < S4) bnext = in[(s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
-                __builtin_amdgcn_sched_barrier(0);                   // keep the ds_read above this block's MFMAs
+                if (s4 + 1 < S4) bnext = buf[(s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
+                __builtin_amdgcn_sched_barrier(0);                    // keep the ds_read above this block's MFMAs
                 // k-step outer, tile inner: consecutive MFMAs are independent chains (40-cycle dependent latency)
 #pragma unroll
                 for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].x, bcur.x, acc[i], 0, 0, 0);
@@ -288,18 +288,19 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             }
             STAMP(m2);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
+            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
             STAMP(m2b);
-            __syncthreads();
-            STAMP(m3);
+            if (l == 0) { STAMP_ADD(4, m0, m1); }
             STAMP_ADD(5, m1, m2);
             STAMP_ADD(6, m2, m2b);
-            STAMP_ADD(7, m2b, m3);
-            f32x4* t = in; in = out; out = t;
+            f32x4* t = buf; buf = other; other = t;
         }
     } else {
         // weights streamed from global memory (L2-resident), any number of layers
         for (int l = 1; l < P.n_hidden; ++l) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            __syncthreads();
             const f32x4* W = P.Wl[l - 1];
             const f32x4* bb = P.bl[l - 1];
             f32x4 acc[NTW];
@@ -307,7 +308,7 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             for (int i = 0; i < NTW; ++i) acc[i] = bb[(wave * NTW + i) * 64 + lane];
 #pragma unroll 2
             for (int s4 = 0; s4 < S4; ++s4) {
-                f32x4 b = in[s4 * 64 + lane];
+                f32x4 b = buf[s4 * 64 + lane];
                 f32x4 a[NTW];
 #pragma unroll
                 for (int i = 0; i < NTW; ++i) a[i] = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
@@ -321,39 +322,34 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
                 for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) out[(wave * NTW + i) * 64 + lane] = act4(P.act, acc[i]);
-            __syncthreads();
-            f32x4* t = in; in = out; out = t;
+            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
+            f32x4* t = buf; buf = other; other = t;
         }
     }
-    // heads: wave w sums its quarter of the hidden units (chain from 0), partials combined in fixed order
+    // heads: wave w sums its quarter of the hidden units (chain from 0) straight from its registers
     {
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            int s4 = wave * NTW + i;
-            f32x4 a = (NREG > 0) ? wr.wh[i] : P.Whead[s4 * 64 + lane];
-            acc = mfma4(a, in[s4 * 64 + lane], acc);
+            f32x4 a = (NREG > 0) ? wr.wh[i] : P.Whead[(wave * NTW + i) * 64 + lane];
+            acc = mfma4(a, h[i], acc);
         }
         parts[wave * 64 + lane] = acc;
     }
     __syncthreads();
-    {
-        int tid = wave * 64 + lane;
-        int tree = tid & 15, o = tid >> 4;
-        if (o < P.n_out) {
-            float total = s_bhead[o];
-            int idx = (o >> 2) * 16 + tree;
+}
+
+// network output o of tree tl: bias + the four waves' partial sums, added in wave order (the oracle's summation order)
+__device__ __forceinline__ float head_output(const f32x4* parts, const float* s_bhead, int tl, int o) {
+    float total = s_bhead[o];
+    const int idx = (o >> 2) * 16 + tl;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                f32x4 pv = parts[w * 64 + idx];
-                float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
-                total = total + p;
-            }
-            outs[tree * 16 + o] = total;
-        }
+    for (int w = 0; w < 4; ++w) {
+        f32x4 pv = parts[w * 64 + idx];
+        float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
+        total = total + p;
     }
-    __syncthreads();
+    return total;
 }
 
 // ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
@@ -524,7 +520,6 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     typedef typename TreeStore<TLDS>::Id Id;
     __shared__ f32x4 s_parts[4 * 64];
     __shared__ float s_obsT[4 * 16];
-    __shared__ float s_outs[16 * 16];
     __shared__ float s_bhead[16];
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, two activation buffers, (TLDS) the 16 trees' hot records
 
@@ -637,9 +632,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         int any = __syncthreads_or(need_eval ? 1 : 0);
         STAMP(t_b);
 #ifdef AZG_STAMPS
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, s_bhead, wave, lane, st_acc);
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, wave, lane, st_acc);
 #else
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_outs, s_bhead, wave, lane);
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, wave, lane);
 #endif
         STAMP(t_c);
 
@@ -647,10 +642,10 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         if (live) {
             float V = 0.0f;
             if (need_eval) {
-                V = s_outs[tl * 16 + 0];
+                V = head_output(s_parts, s_bhead, tl, 0);
                 if (CONT) {
-                    float mu = s_outs[tl * 16 + 1];
-                    float ls = s_outs[tl * 16 + 2];
+                    float mu = head_output(s_parts, s_bhead, tl, 1);
+                    float ls = head_output(s_parts, s_bhead, tl, 2);
                     ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
                     float sg = azg_expf(ls);
                     if (sub == 0) { cold[leaf].V = V; cold[leaf].mu = mu; cold[leaf].sg = sg; }
@@ -672,14 +667,14 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                 } else {
                     // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
                     const int A = P.A;
-                    float mx = s_outs[tl * 16 + 1];
-                    for (int a = 1; a < A; ++a) { float v = s_outs[tl * 16 + 1 + a]; mx = v > mx ? v : mx; }
+                    float mx = head_output(s_parts, s_bhead, tl, 1);
+                    for (int a = 1; a < A; ++a) { float v = head_output(s_parts, s_bhead, tl, 1 + a); mx = v > mx ? v : mx; }
                     float sum = 0.0f;
-                    for (int a = 0; a < A; ++a) sum = sum + azg_expf(s_outs[tl * 16 + 1 + a] - mx);
+                    for (int a = 0; a < A; ++a) sum = sum + azg_expf(head_output(s_parts, s_bhead, tl, 1 + a) - mx);
                     int k0 = nrec;
                     nrec += A;
                     if (sub < A) {
-                        float pr = azg_expf(s_outs[tl * 16 + 1 + sub] - mx) / sum;
+                        float pr = azg_expf(head_output(s_parts, s_bhead, tl, 1 + sub) - mx) / sum;
                         Rec h = make_edge<Rec>((double)V, leaf);
                         clear_pad(h);
                         ts.hot[k0 + sub] = h;

@@ -44,7 +44,7 @@ def main():
         v = buf[:, i].astype(np.float64)
         print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
     print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
-    for i, nm in zip(range(4, 11), ["  mlp: layer0 + barrier", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  mlp: hidden barrier",
+    for i, nm in zip(range(4, 11), ["  mlp: layer0+ELU+publish", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  (unused)",
                                      "  A: finish leaf", "  B: descent", "  B: widen+env step+create"]):
         v = buf[:, i].astype(np.float64)
         print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
