@@ -1,0 +1,77 @@
+"""Property tests: size-independent invariants of a search, on random configurations.
+CPU: the oracle (hypothesis-driven).  GPU: the same invariants on the HIP engine at BASELINE config B (CartPole)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle_lib as O
+from alphazero_gym_amd import _capi
+
+
+def check_invariants(eng, res, dump, n_sims, carry, cont, c_pw=1.0, kappa=0.5):
+    B = eng.n_trees
+    nrec = dump["n_records"]
+    for t in range(B):
+        n = int(nrec[t])
+        par, en, nn, fl = dump["parent"][t][:n], dump["edge_n"][t][:n], dump["node_n"][t][:n], dump["node_flags"][t][:n]
+        assert par[0] == -1 and (par[1:] >= 0).all() and (par[1:] < np.arange(1, n)).all()   # parents precede children
+        acc = np.zeros(n, np.int64)
+        np.add.at(acc, par[1:], en[1:])
+        expect = nn.astype(np.int64).copy()
+        expect[0] -= int(carry[t]) if carry is not None else 0
+        np.testing.assert_array_equal(acc, expect)                     # node.n == sum of child edge counts (+ carried root count)
+        assert int(en[1:][par[1:] == 0].sum()) == n_sims               # every trace passes through the root
+        assert ((fl[en > 0] & 1) == 1).all()                           # visited edges have a child node
+        term = (fl & 2) != 0
+        assert not term[0] and (acc[term] == 0).all()                  # terminal nodes are never expanded further
+        k = int(res["n_children"][t])
+        assert res["counts"][t, :k].sum() == n_sims
+        if cont:
+            assert k == max(1, int(np.ceil(c_pw * n_sims ** kappa)))   # progressive widening at the root (Pendulum never terminates)
+            assert n == n_sims + 1 + (k - int((en[1:][par[1:] == 0] > 0).sum()))
+        w, q = dump["edge_W"][t][:n], dump["edge_Q"][t][:n]
+        vis = en > 0
+        np.testing.assert_array_equal(q[vis], w[vis] / en[vis])          # Q = W / n exactly (states.py:110-112)
+        np.testing.assert_allclose(res["v_target"][t], res["Q"][t, :k].max())
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n_sims=st.integers(1, 70), c_uct=st.floats(0.01, 2.0), kappa=st.floats(0.3, 0.9), gamma=st.floats(0.8, 1.0),
+       seed=st.integers(0, 2 ** 31), hidden=st.sampled_from([[64], [64, 64], [128, 128]]))
+def test_continuous_search_invariants(n_sims, c_uct, kappa, gamma, seed, hidden):
+    e = O.OracleEngine(env_id=2, mode=1, n_trees=5, n_sims=n_sims, c_uct=c_uct, gamma=gamma, c_pw=1.0, kappa=kappa, seed=seed)
+    e.set_weights(_capi.make_desc(3, hidden, 2, "elu"), O.make_weights(seed % 1000, 3, hidden, 2))
+    e.search(e.synthetic_roots())
+    check_invariants(e, e.results(), e.dump_tree(), n_sims, None, True, 1.0, kappa)
+    e.close()
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n_sims=st.integers(1, 70), c_uct=st.floats(0.1, 30.0), gamma=st.floats(0.8, 1.0), eps=st.sampled_from([0.0, 0.1, 0.5]),
+       seed=st.integers(0, 2 ** 31), carry=st.integers(0, 60))
+def test_discrete_search_invariants(n_sims, c_uct, gamma, eps, seed, carry):
+    e = O.OracleEngine(env_id=0, mode=0, n_trees=5, n_sims=n_sims, c_uct=c_uct, gamma=gamma, epsilon=eps, num_actions=2, seed=seed)
+    e.set_weights(_capi.make_desc(4, [64, 64], 2, "relu"), O.make_weights(seed % 1000, 4, [64, 64], 2, scale=2.0))
+    roots = e.synthetic_roots()
+    roots[1] = [2.3, 1.2, 0.0, 0.0]
+    c = np.full(5, min(carry, 3 * n_sims), np.int32)
+    e.search(roots, c)
+    check_invariants(e, e.results(), e.dump_tree(), n_sims, c, False)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_full_size_cartpole_invariants_on_gpu():
+    """BASELINE config B: CartPole, 4096 trees, n_sims 100, 2x128 ReLU."""
+    from alphazero_gym_amd import _native
+    e = _native.HipEngine(env_id=0, mode=0, n_trees=4096, n_sims=100, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+    e.set_weights(_capi.make_desc(4, [128, 128], 2, "relu"), O.make_weights(34, 4, [128, 128], 2))
+    roots = e.synthetic_roots()
+    e.search(roots)
+    res, dump = e.results(), e.dump_tree()
+    sub = np.arange(0, 4096, 37)
+    class V:   # view of a subset of trees
+        n_trees = len(sub)
+    check_invariants(V, {k: v[sub] for k, v in res.items()}, {k: v[sub] for k, v in dump.items()}, 100, None, False)
+    assert (res["counts"].sum(1) == 100).all()
+    e.close()
