@@ -77,6 +77,7 @@ SYMBOLS = [
     "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_search_index", "search",
     "results", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
     "synthetic_roots", "last_search_ms", "upload_roots", "search_resident", "sync",
+    "selfplay_begin", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats",
 ]
 
 
@@ -108,6 +109,11 @@ def bind(lib, prefix):
     f["upload_roots"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     f["search_resident"].argtypes = [vp]
     f["sync"].argtypes = [vp]
+    f["selfplay_begin"].argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    f["selfplay_step"].argtypes = [vp]
+    f["selfplay_row_len"].argtypes = [vp]
+    f["selfplay_rows"].argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int32]
+    f["selfplay_stats"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     return f
 
 
@@ -300,6 +306,39 @@ class Engine:
             _ptr(d["node_n"], C.c_int32), _ptr(d["node_r"], C.c_double), _ptr(d["node_V"], C.c_float),
             _ptr(d["node_flags"], C.c_uint8)))
         return d
+
+
+def _selfplay_methods():
+    def selfplay_begin(self, max_episode_length, deterministic=False, capacity_steps=64):
+        """Start device-resident self-play: games reset to their fixed-seed initial states (include/azgym.h)."""
+        self._check(self._f["selfplay_begin"](self._h, int(max_episode_length), int(bool(deterministic)), int(capacity_steps)))
+        self._sp_cap = int(capacity_steps)
+
+    def selfplay_step(self):
+        """One search + final action + env step + bookkeeping for all games, entirely on the device (asynchronous)."""
+        self._check(self._f["selfplay_step"](self._h))
+
+    def selfplay_rows(self, clear=True):
+        """Replay rows [steps*B, row_len] float32 of the steps since the last clear: obs | actions[K] | counts[K] | Q[K] | V."""
+        rl = self._f["selfplay_row_len"](self._h)
+        rows = np.empty((self._sp_cap * self.n_trees, rl), np.float32)
+        n = self._f["selfplay_rows"](self._h, _ptr(rows, C.c_float), rows.shape[0], int(bool(clear)))
+        if n < 0:
+            self._check(n)
+        return rows[:n]
+
+    def selfplay_stats(self):
+        fsum = np.empty((self.n_trees,), np.float64)
+        fcnt = np.empty((self.n_trees,), np.int32)
+        state = np.empty((self.n_trees, self.s_env), np.float64)
+        self._check(self._f["selfplay_stats"](self._h, _ptr(fsum, C.c_double), _ptr(fcnt, C.c_int32), _ptr(state, C.c_double)))
+        return fsum, fcnt, state
+
+    for fn in (selfplay_begin, selfplay_step, selfplay_rows, selfplay_stats):
+        setattr(Engine, fn.__name__, fn)
+
+
+_selfplay_methods()
 
 
 def pw_table(c_pw, kappa, n):

@@ -923,6 +923,98 @@ __global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions
     }
 }
 
+// One self-play step after a search, one thread per game: replay row, the agent's final action rule, the real env step,
+// episode bookkeeping and the next search's root (the CPU oracle restates the same arithmetic for the parity tests).
+struct SelfPlay {
+    int max_len, deterministic;
+    unsigned step_idx;
+    int* t; int* episode; int* fcnt;
+    double* ret; double* fsum;
+    float* rows;          // this step's block [B][row_len]
+    double* roots; int* carry;
+};
+
+__global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
+    int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= P.B) return;
+    const size_t tb = (size_t)tree * P.R;
+    const RecL* hot = P.hot + tb;
+    const unsigned short* child = P.child + tb * P.Kp;
+    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
+    const unsigned gtree = (unsigned)(P.tree_base + tree);
+    const int S = P.S, K = Kmax, RL = S_obs + 3 * Kmax + 1;
+    double root[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < S; ++k) root[k] = sp.roots[(size_t)tree * S + k];
+    float* row = sp.rows + (size_t)tree * RL;
+    const RecL r0 = hot[0];
+    const int nc = r0.n_child;
+    float obs[4];
+    double sn;
+    if (env_id == AZG_ENV_CARTPOLE) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
+    double qmax = 0.0, onp = 0.0;
+    long tot = 0;
+    int cmax = 0, amax = 0;
+    for (int a = 0; a < nc; ++a) tot += hot[cont ? (int)child[a] : (int)r0.first + a].edge_n;
+    for (int a = 0; a < K; ++a) {
+        int k = a < nc ? (cont ? (int)child[a] : (int)r0.first + a) : -1;
+        RecL h = hot[k >= 0 ? k : 0];
+        row[S_obs + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
+        row[S_obs + K + a] = k >= 0 ? (float)h.edge_n : 0.0f;
+        row[S_obs + 2 * K + a] = k >= 0 ? (float)h.Q : 0.0f;
+        if (k >= 0) {
+            if (a == 0 || h.Q > qmax) qmax = h.Q;
+            if (!cont) onp += ((double)h.edge_n / (double)tot) * h.Q;
+            if (a == 0 || h.edge_n > cmax) { cmax = h.edge_n; amax = a; }
+        }
+    }
+    if (cont)
+        for (int a = 0; a < nc; ++a)
+            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+    row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
+    int pick = amax;
+    if (!cont && !sp.deterministic) {
+        azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+        double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+        double sum = 0.0;
+        for (int a = 0; a < nc; ++a) sum = sum + (double)hot[(int)r0.first + a].edge_n / (double)cmax;
+        double cum = 0.0;
+        pick = nc - 1;
+        for (int a = 0; a < nc; ++a) {
+            cum = cum + ((double)hot[(int)r0.first + a].edge_n / (double)cmax) / sum;
+            if (u < cum) { pick = a; break; }
+        }
+    }
+    const int krec = cont ? (int)child[pick] : (int)r0.first + pick;
+    double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
+    int done;
+    if (env_id == AZG_ENV_CARTPOLE) {
+        cartpole_step(root, pick, ns, &r, &done);
+    } else {
+        double s1, c1;
+        azg_sincos(root[0], &s1, &c1);
+        pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, s1, P.action[tb + krec], ns, &r, &done);
+    }
+    double ret = sp.ret[tree] + r;
+    int t = sp.t[tree] + 1;
+    if (done || t >= sp.max_len) {
+        sp.fsum[tree] = sp.fsum[tree] + ret;
+        sp.fcnt[tree] += 1;
+        ret = 0.0;
+        t = 0;
+        int ep = sp.episode[tree] + 1;
+        sp.episode[tree] = ep;
+        azg_reset_state(P.seed, gtree, (unsigned)ep, env_id == AZG_ENV_CARTPOLE, ns);
+        sp.carry[tree] = 0;
+    } else {
+        RecL hk = hot[krec];
+        sp.carry[tree] = (!cont && (hk.flags & FLAG_EXPANDED)) ? hk.node_n : 0;
+    }
+    sp.ret[tree] = ret;
+    sp.t[tree] = t;
+    for (int k = 0; k < S; ++k) sp.roots[(size_t)tree * S + k] = ns[k];
+}
+
 __global__ void math_selftest_kernel(int fn_id, const double* in, double* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -978,6 +1070,10 @@ struct azg_engine {
     float* d_rootV; float* d_rootdist;
     double* d_roots; int* d_carry;
     uint32_t search_idx;
+    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
+    uint32_t sp_step_idx;
+    int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
+    std::vector<void*> sp_allocs;
     int searched, results_valid;
     float last_ms;
     std::string err;
@@ -1076,6 +1172,7 @@ void azg_engine_destroy(azg_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->dev_allocs) (void)hipFree(p);
     for (void* p : e->weight_allocs) (void)hipFree(p);
+    for (void* p : e->sp_allocs) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1098,7 +1195,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     azg_engine* e = new azg_engine();
     e->cfg = *cfg;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
-    e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f;
+    e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
     e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 3;
     const int ns = cfg->n_sims;
@@ -1466,15 +1563,79 @@ int azg_obs_dim(const azg_engine* e) { return e ? e->S_obs : AZG_E_INVALID; }
 
 int azg_synthetic_roots(azg_engine* e, double* roots) {
     if (!e || !roots) return AZG_E_INVALID;
-    const double pi = 3.141592653589793;
-    for (int i = 0; i < e->cfg.n_trees; ++i) {
-        azg_u32x4 b = azg_draw(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, 0u, AZG_STREAM_ROOT);
-        double u[4];
-        for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
-        double* r = roots + (size_t)i * e->S_env;
-        if (e->cfg.env_id == AZG_ENV_CARTPOLE) for (int k = 0; k < 4; ++k) r[k] = -0.05 + 0.1 * u[k];
-        else { r[0] = -pi + 2.0 * pi * u[0]; r[1] = -1.0 + 2.0 * u[1]; }
-    }
+    for (int i = 0; i < e->cfg.n_trees; ++i)
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, roots + (size_t)i * e->S_env);
+    return AZG_OK;
+}
+
+int azg_selfplay_row_len(const azg_engine* e) { return e ? e->S_obs + 3 * e->Kmax + 1 : AZG_E_INVALID; }
+
+int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
+    if (!e || max_episode_length < 1 || capacity_steps < 1) return AZG_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (void* p : e->sp_allocs) (void)hipFree(p);
+    e->sp_allocs.clear();
+    const size_t B = e->cfg.n_trees;
+    e->sp_row = e->S_obs + 3 * e->Kmax + 1;
+    if (dalloc(e, &e->d_sp_t, B, e->sp_allocs) || dalloc(e, &e->d_sp_episode, B, e->sp_allocs) || dalloc(e, &e->d_sp_fcnt, B, e->sp_allocs) ||
+        dalloc(e, &e->d_sp_ret, B, e->sp_allocs) || dalloc(e, &e->d_sp_fsum, B, e->sp_allocs) ||
+        dalloc(e, &e->d_sp_rows, (size_t)capacity_steps * B * e->sp_row, e->sp_allocs))
+        return AZG_E_DEVICE;
+    HIPCHK(e, hipMemset(e->d_sp_t, 0, B * 4));
+    HIPCHK(e, hipMemset(e->d_sp_episode, 0, B * 4));
+    HIPCHK(e, hipMemset(e->d_sp_fcnt, 0, B * 4));
+    HIPCHK(e, hipMemset(e->d_sp_ret, 0, B * 8));
+    HIPCHK(e, hipMemset(e->d_sp_fsum, 0, B * 8));
+    std::vector<double> roots(B * e->S_env);
+    azg_synthetic_roots(e, roots.data());
+    HIPCHK(e, hipMemcpy(e->d_roots, roots.data(), roots.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemset(e->d_carry, 0, B * 4));
+    e->sp_on = 1; e->sp_max_len = max_episode_length; e->sp_det = deterministic; e->sp_cap = capacity_steps; e->sp_steps = 0;
+    e->sp_step_idx = 0;
+    return AZG_OK;
+}
+
+int azg_selfplay_step(azg_engine* e) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
+    if (e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
+    int rc = azg_search_resident(e);
+    if (rc) return rc;
+    SelfPlay sp;
+    sp.max_len = e->sp_max_len; sp.deterministic = e->sp_det; sp.step_idx = e->sp_step_idx;
+    sp.t = e->d_sp_t; sp.episode = e->d_sp_episode; sp.fcnt = e->d_sp_fcnt; sp.ret = e->d_sp_ret; sp.fsum = e->d_sp_fsum;
+    sp.rows = e->d_sp_rows + (size_t)e->sp_steps * e->cfg.n_trees * e->sp_row;
+    sp.roots = e->d_roots; sp.carry = e->d_carry;
+    const int B = e->cfg.n_trees;
+    hipLaunchKernelGGL(selfplay_kernel, dim3((B + 127) / 128), dim3(128), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
+    HIPCHK(e, hipGetLastError());
+    e->sp_steps += 1;
+    e->sp_step_idx += 1;
+    return AZG_OK;
+}
+
+int azg_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    size_t n = (size_t)e->sp_steps * e->cfg.n_trees;
+    if (n > max_rows) n = max_rows;
+    if (rows && n) HIPCHK(e, hipMemcpy(rows, e->d_sp_rows, n * e->sp_row * 4, hipMemcpyDeviceToHost));
+    if (clear) e->sp_steps = 0;
+    return (int)n;
+}
+
+int azg_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_state) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    size_t B = e->cfg.n_trees;
+    D2H(fsum, e->d_sp_fsum, B * 8);
+    D2H(fcnt, e->d_sp_fcnt, B * 4);
+    D2H(env_state, e->d_roots, B * e->S_env * 8);
     return AZG_OK;
 }
 

@@ -215,11 +215,29 @@ AZG_HD float azg_u01(uint32_t x) {
 
 #define AZG_STREAM_PW 0u      /* progressive-widening action noise, N(0,1) */
 #define AZG_STREAM_EPS 1u     /* epsilon-greedy: v[0] -> u, v[1] -> random child */
-#define AZG_STREAM_ROOT 2u    /* synthetic root states (bench / self-play resets) */
+#define AZG_STREAM_ROOT 2u    /* synthetic root states (bench / self-play resets): counter (tree, episode, 0, stream) */
+#define AZG_STREAM_ACT 3u     /* self-play: final action sampled from the visit counts: counter (tree, step, 0, stream) */
+
+/* fixed-seed reset state of game `tree`, episode `episode` (Pendulum theta~U(-pi,pi), theta_dot~U(-1,1);
+ * CartPole ~U(-0.05,0.05)^4); env 0 = CartPole, else Pendulum */
+AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s);
 
 /* the engine's draw #`draw` of stream `stream` for (global tree id, search index) */
 AZG_HD azg_u32x4 azg_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, uint32_t stream) {
     return azg_philox4x32(tree, search, draw, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s) {
+    const double pi = 3.141592653589793;
+    azg_u32x4 b = azg_draw(seed, tree, episode, 0u, AZG_STREAM_ROOT);
+    double u[4];
+    for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
+    if (env_is_cartpole) {
+        for (int k = 0; k < 4; ++k) s[k] = -0.05 + 0.1 * u[k];
+    } else {
+        s[0] = -pi + 2.0 * pi * u[0];
+        s[1] = -1.0 + 2.0 * u[1];
+    }
 }
 
 /* standard normal (Box-Muller, cosine branch) */

@@ -135,6 +135,21 @@ int azg_upload_roots(azg_engine* e, const double* root_env_state, const int32_t*
 int azg_search_resident(azg_engine* e);
 int azg_sync(azg_engine* e);
 
+/* Device-resident self-play (the run loop of run_continuous.py:111-142 / run_discrete.py:94-122 for B games in lock step):
+ * games live on the device; one azg_selfplay_step = one search from the current roots, then per game: the agent's final
+ * action rule (continuous: most visited root action, first index on ties, agents.py:533; discrete: sampled in proportion
+ * to counts/max(counts), temperature 1, agents.py:300-301, or arg-max when deterministic), one replay row
+ * [obs | actions[Kmax] | counts[Kmax] | Q[Kmax] | V_target] (float32) appended to a device ring buffer, the real env
+ * step, episode bookkeeping (reset on termination or after max_episode_length steps) and the next search's root
+ * (discrete: with the reused root's carried visit count, MCTSDiscrete.forward mcts.py:495-526). */
+int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps);
+int azg_selfplay_step(azg_engine* e);
+int azg_selfplay_row_len(const azg_engine* e);
+/* rows of the steps played since the last clear, ordered [step][tree]; returns the number of rows copied */
+int azg_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear);
+/* per game: sum of the returns of finished episodes, number of finished episodes, current env state [B][S_env] */
+int azg_selfplay_stats(azg_engine* e, double* finished_return_sum, int32_t* finished_episodes, double* env_state);
+
 /* bit-exactness self test of azg_math.h on the device: evaluates fn_id on n inputs */
 int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, size_t n);
 

@@ -80,6 +80,10 @@ struct azg_engine {
     int32_t* carry;
     uint32_t search_idx;
     int searched;
+    /* self-play */
+    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
+    uint32_t sp_step_idx;
+    int32_t* sp_t; int32_t* sp_episode; int32_t* sp_fcnt; double* sp_ret; double* sp_fsum; float* sp_rows;
     char err[256];
 };
 
@@ -248,6 +252,7 @@ void azo_engine_destroy(azg_engine* e) {
     if (e->trees) { for (int i = 0; i < e->cfg.n_trees; ++i) free_tree(&e->trees[i]); free(e->trees); }
     for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.b[l]); }
     free(e->mlp.Wh); free(e->mlp.bh); free(e->pw_need); free(e->roots); free(e->carry);
+    free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
     free(e);
 }
 
@@ -633,15 +638,123 @@ int azo_obs_dim(const azg_engine* e) { return e ? e->S_obs : AZG_E_INVALID; }
 /* synthetic fixed-seed roots */
 int azo_synthetic_roots(azg_engine* e, double* roots) {
     if (!e || !roots) return AZG_E_INVALID;
-    const double pi = 3.141592653589793;
-    for (int i = 0; i < e->cfg.n_trees; ++i) {
-        azg_u32x4 b = azg_draw(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, 0u, AZG_STREAM_ROOT);
-        double u[4];
-        for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
-        double* r = roots + (size_t)i * e->S_env;
-        if (e->cfg.env_id == AZG_ENV_CARTPOLE) for (int k = 0; k < 4; ++k) r[k] = -0.05 + 0.1 * u[k];
-        else { r[0] = -pi + 2.0 * pi * u[0]; r[1] = -1.0 + 2.0 * u[1]; }
+    for (int i = 0; i < e->cfg.n_trees; ++i)
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, roots + (size_t)i * e->S_env);
+    return AZG_OK;
+}
+
+/* ------------------------------------------------------------------ self-play (run_continuous.py:111-142, run_discrete.py:94-122) */
+
+int azo_selfplay_row_len(const azg_engine* e) { return e ? e->S_obs + 3 * e->Kmax + 1 : AZG_E_INVALID; }
+
+int azo_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
+    if (!e || max_episode_length < 1 || capacity_steps < 1) return AZG_E_INVALID;
+    int B = e->cfg.n_trees;
+    free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
+    e->sp_row = e->S_obs + 3 * e->Kmax + 1;
+    e->sp_t = (int32_t*)calloc(B, 4); e->sp_episode = (int32_t*)calloc(B, 4); e->sp_fcnt = (int32_t*)calloc(B, 4);
+    e->sp_ret = (double*)calloc(B, 8); e->sp_fsum = (double*)calloc(B, 8);
+    e->sp_rows = (float*)calloc((size_t)capacity_steps * B * e->sp_row, 4);
+    e->sp_on = 1; e->sp_max_len = max_episode_length; e->sp_det = deterministic; e->sp_cap = capacity_steps; e->sp_steps = 0;
+    e->sp_step_idx = 0;
+    for (int i = 0; i < B; ++i)
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, e->roots + (size_t)i * e->S_env);
+    memset(e->carry, 0, 4 * (size_t)B);
+    return AZG_OK;
+}
+
+int azo_selfplay_step(azg_engine* e) {
+    if (!e || !e->sp_on) return e ? fail(e, AZG_E_STATE, "azo_selfplay_begin has not been called") : AZG_E_INVALID;
+    if (e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
+    int rc = azo_search_resident(e);
+    if (rc) return rc;
+    const int B = e->cfg.n_trees, K = e->Kmax, S = e->S_env, So = e->S_obs, RL = e->sp_row;
+    const int cont = e->cfg.mode == AZG_MODE_CONTINUOUS;
+    float* rows = e->sp_rows + (size_t)e->sp_steps * B * RL;
+    for (int i = 0; i < B; ++i) {
+        tree_t* t = &e->trees[i];
+        const uint32_t gtree = (uint32_t)(e->cfg.tree_id_base + i);
+        double* root = e->roots + (size_t)i * S;
+        float* row = rows + (size_t)i * RL;
+        int nc = t->n_child[0];
+        /* replay row */
+        env_obs(e->cfg.env_id, root, row);
+        double qmax = 0.0, onp = 0.0;
+        long tot = 0;
+        int cmax = 0, amax = 0;
+        for (int a = 0; a < nc; ++a) tot += t->edge_n[t->child[a]];
+        for (int a = 0; a < K; ++a) {
+            int k = a < nc ? t->child[a] : -1;
+            row[So + a] = k >= 0 ? t->edge_action[k] : 0.0f;
+            row[So + K + a] = k >= 0 ? (float)t->edge_n[k] : 0.0f;
+            row[So + 2 * K + a] = k >= 0 ? (float)t->edge_Q[k] : 0.0f;
+            if (k >= 0) {
+                if (a == 0 || t->edge_Q[k] > qmax) qmax = t->edge_Q[k];
+                if (!cont) onp += ((double)t->edge_n[k] / (double)tot) * t->edge_Q[k];
+                if (a == 0 || t->edge_n[k] > cmax) { cmax = t->edge_n[k]; amax = a; }   /* first index on ties */
+            }
+        }
+        if (cont)
+            for (int a = 0; a < nc; ++a)
+                for (int b = 0; b < nc; ++b) onp += ((double)t->edge_n[t->child[b]] / (double)tot) * t->edge_Q[t->child[a]];
+        row[So + 3 * K] = (float)(e->cfg.v_target == AZG_VT_ON_POLICY ? onp : qmax);
+        /* final action (agents.py:294-301, 524-535) */
+        int pick = amax;
+        if (!cont && !e->sp_det) {
+            azg_u32x4 b = azg_draw(e->cfg.seed, gtree, e->sp_step_idx, 0u, AZG_STREAM_ACT);
+            double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+            /* stable_normalizer(counts, 1.0) (helpers.py:26-27): x = c/max; pi = x/sum(x); inverse-CDF with u */
+            double sum = 0.0;
+            for (int a = 0; a < nc; ++a) sum = sum + (double)t->edge_n[t->child[a]] / (double)cmax;
+            double cum = 0.0;
+            pick = nc - 1;
+            for (int a = 0; a < nc; ++a) {
+                cum = cum + ((double)t->edge_n[t->child[a]] / (double)cmax) / sum;
+                if (u < cum) { pick = a; break; }
+            }
+        }
+        int krec = t->child[pick];
+        /* real env step */
+        double ns[4], r;
+        int done;
+        if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(root, pick, ns, &r, &done);
+        else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, root, t->edge_action[krec], ns, &r, &done);
+        e->sp_ret[i] = e->sp_ret[i] + r;
+        e->sp_t[i] += 1;
+        if (done || e->sp_t[i] >= e->sp_max_len) {
+            e->sp_fsum[i] = e->sp_fsum[i] + e->sp_ret[i];
+            e->sp_fcnt[i] += 1;
+            e->sp_ret[i] = 0.0;
+            e->sp_t[i] = 0;
+            e->sp_episode[i] += 1;
+            azg_reset_state(e->cfg.seed, gtree, (uint32_t)e->sp_episode[i], e->cfg.env_id == AZG_ENV_CARTPOLE, root);
+            e->carry[i] = 0;
+        } else {
+            memcpy(root, ns, sizeof(double) * S);
+            /* MCTSDiscrete.forward (mcts.py:495-526): a reused root keeps its visit count; continuous trees are rebuilt */
+            e->carry[i] = (!cont && (t->flags[krec] & FLAG_EXPANDED)) ? t->node_n[krec] : 0;
+        }
     }
+    e->sp_steps += 1;
+    e->sp_step_idx += 1;
+    return AZG_OK;
+}
+
+int azo_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear) {
+    if (!e || !e->sp_on) return AZG_E_STATE;
+    size_t n = (size_t)e->sp_steps * e->cfg.n_trees;
+    if (n > max_rows) n = max_rows;
+    if (rows) memcpy(rows, e->sp_rows, n * e->sp_row * 4);
+    if (clear) e->sp_steps = 0;
+    return (int)n;
+}
+
+int azo_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_state) {
+    if (!e || !e->sp_on) return AZG_E_STATE;
+    int B = e->cfg.n_trees;
+    if (fsum) memcpy(fsum, e->sp_fsum, 8 * (size_t)B);
+    if (fcnt) memcpy(fcnt, e->sp_fcnt, 4 * (size_t)B);
+    if (env_state) memcpy(env_state, e->roots, 8 * (size_t)B * e->S_env);
     return AZG_OK;
 }
 
