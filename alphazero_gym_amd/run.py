@@ -184,6 +184,58 @@ class BatchedSelfPlay:
         return torch.cat(rows, 0)
 
 
+class DeviceSelfPlay:
+    """The same loop with everything but the optimiser on the GPU (azg_selfplay_* in include/azgym.h): games, final action
+    rule, env step, episode resets and the replay ring live on the device; the host only downloads rows to train on."""
+
+    def __init__(self, policy, *, game: str, n_games: int, n_rollouts: int, c_uct: float, gamma: float = 1.0, epsilon: float = 0.0,
+                 c_pw: float = 1.0, kappa: float = 0.5, V_target_policy: str = "off_policy", max_episode_length: int = 200,
+                 deterministic: bool = False, capacity_steps: int = 64, seed: int = 34, rank: int = 0, device_id: int = 0):
+        self.continuous = game.lower().startswith("pendulum")
+        if self.continuous:
+            env_id = _capi.ENV_PENDULUM_V0 if game.endswith("v0") else _capi.ENV_PENDULUM_V1
+            self.mcts = BatchedMCTS(policy, env_id=env_id, mode=_capi.MODE_CONTINUOUS, n_trees=n_games, n_rollouts=n_rollouts, c_uct=c_uct,
+                                    gamma=gamma, epsilon=epsilon, c_pw=c_pw, kappa=kappa, V_target_policy=V_target_policy,
+                                    action_bound=float(policy.action_bound), seed=seed, tree_id_base=rank * n_games, device_id=device_id)
+        else:
+            self.mcts = BatchedMCTS(policy, env_id=_capi.ENV_CARTPOLE, mode=_capi.MODE_DISCRETE, n_trees=n_games, n_rollouts=n_rollouts,
+                                    c_uct=c_uct, gamma=gamma, epsilon=epsilon, num_actions=policy.num_actions,
+                                    V_target_policy=V_target_policy, seed=seed, tree_id_base=rank * n_games, device_id=device_id)
+        self.engine = self.mcts.engine
+        self.capacity = capacity_steps
+        self.engine.selfplay_begin(max_episode_length, deterministic, capacity_steps)
+
+    def collect(self, n_steps: int) -> torch.Tensor:
+        """Play n_steps (<= capacity) and return this rank's replay rows as float32 [n_steps * B, row]."""
+        assert n_steps <= self.capacity
+        self.mcts.sync_weights()
+        for _ in range(n_steps):
+            self.engine.selfplay_step()
+        return torch.from_numpy(self.engine.selfplay_rows(clear=True).copy())
+
+    def mean_finished_return(self) -> float:
+        fsum, fcnt, _ = self.engine.selfplay_stats()
+        return float(fsum.sum() / max(int(fcnt.sum()), 1))
+
+
+def train_on_rows(agent, rows: torch.Tensor, state_dim: int, K: int, batch_size: int = 32, shuffle_seed: int = 0) -> Dict[str, float]:
+    """One epoch of minibatch updates (agent.update) over replay rows gathered from all ranks; the last batch absorbs the
+    remainder like ReplayBuffer.__next__."""
+    s, a, c, q, v = D.unpack_replay_rows(rows, state_dim, K)
+    n = s.shape[0]
+    order = np.random.RandomState(shuffle_seed).permutation(n)
+    sums: Dict[str, float] = {}
+    i = 0
+    while i < n:
+        j = n if i + 2 * batch_size > n else i + batch_size
+        idx = order[i:j]
+        info = agent.update((s[idx].copy(), a[idx].copy(), c[idx].copy(), q[idx].copy(), v[idx].astype(np.float64)))
+        for k_, val in info.items():
+            sums[k_] = sums.get(k_, 0.0) + val
+        i = j
+    return sums
+
+
 def main():
     ap = argparse.ArgumentParser(description="single-game drivers with the reference's loop shape")
     ap.add_argument("kind", choices=["continuous", "discrete"])

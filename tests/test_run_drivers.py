@@ -55,3 +55,23 @@ def test_batched_selfplay_rows_and_episode_bookkeeping(backend):
     sp = run.BatchedSelfPlay(pol, game="CartPole-v1", n_games=5, n_rollouts=12, c_uct=1.5, max_episode_length=50)
     rows = sp.collect(3)
     assert rows.shape == (15, 4 + 3 * 2 + 1)
+
+
+def test_device_selfplay_and_training_round(backend):
+    """games on the device -> rows -> gather (single rank) -> optimiser step -> weights re-synced for the next round"""
+    from alphazero_gym_amd.agent.agents import ContinuousAgent
+    torch.manual_seed(0)
+    pol = dict(_target_="alphazero_gym_amd.network.policies.make_policy", representation_dim=3, action_dim=1, distribution="normal",
+               hidden_dimensions=[64, 64], nonlinearity="elu", num_components=1, action_bound=2.0)
+    mcts = dict(_target_="alphazero_gym_amd.search.mcts.MCTSContinuous", n_rollouts=16, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                V_target_policy="off_policy", device="cpu", root_state=None)
+    ag = ContinuousAgent(policy_cfg=pol, mcts_cfg=mcts, loss_cfg=run.LOSS_TUNED, optimizer_cfg=run.RMSPROP, final_selection="max_visit",
+                         epsilon=0, train_epochs=1, grad_clip=0, device="cpu")
+    sp = run.DeviceSelfPlay(ag.nn, game="Pendulum-v1", n_games=8, n_rollouts=16, c_uct=0.05, max_episode_length=5, capacity_steps=6)
+    rows = D.gather_replay_rows(sp.collect(6))
+    assert rows.shape == (48, 3 + 3 * 4 + 1)
+    before = [p.detach().clone() for p in ag.nn.parameters()]
+    info = run.train_on_rows(ag, rows, 3, 4, batch_size=16)
+    assert np.isfinite(info["loss"]) and any(not torch.equal(a, b) for a, b in zip(before, ag.nn.parameters()))
+    rows2 = sp.collect(2)                       # picks up the new weights
+    assert rows2.shape[0] == 16 and sp.mean_finished_return() < 0
