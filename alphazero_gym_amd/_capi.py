@@ -60,6 +60,8 @@ class AzgMlpDesc(C.Structure):
         ("activation", C.c_int32),
         ("log_std_min", C.c_float),
         ("log_std_max", C.c_float),
+        ("num_components", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -143,6 +145,7 @@ def policy_blob(policy):
     desc.activation = ACT[acts.pop()]
     desc.log_std_min = float(getattr(policy, "log_param_min", -5.0))
     desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
+    desc.num_components = int(getattr(policy, "num_components", 0) or 0)
     parts = []
     for mod in linears + [policy.value_head, policy.dist_head]:
         parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
@@ -150,7 +153,7 @@ def policy_blob(policy):
     return desc, blob
 
 
-def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=2.0):
+def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=2.0, num_components=0):
     desc = AzgMlpDesc()
     desc.struct_size = C.sizeof(AzgMlpDesc)
     desc.in_dim = in_dim
@@ -161,6 +164,7 @@ def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=
     desc.activation = ACT[activation] if isinstance(activation, str) else activation
     desc.log_std_min = log_std_min
     desc.log_std_max = log_std_max
+    desc.num_components = num_components
     return desc
 
 
@@ -201,7 +205,7 @@ class Engine:
         self.max_records = fns["max_records"](self._h)
         self.s_env = fns["env_state_dim"](self._h)
         self.s_obs = fns["obs_dim"](self._h)
-        self.n_dist = num_actions if mode == MODE_DISCRETE else 2
+        self.n_dist = num_actions if mode == MODE_DISCRETE else 2   # 3 * num_components after set_weights with a mixture head
 
     def _check(self, rc):
         if rc != 0:
@@ -224,6 +228,8 @@ class Engine:
     def set_weights(self, desc, blob):
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         self._check(self._f["set_weights"](self._h, C.byref(desc), _ptr(blob, C.c_float), blob.size))
+        if self.mode == MODE_CONTINUOUS:
+            self.n_dist = desc.n_dist
 
     def set_policy(self, policy):
         desc, blob = policy_blob(policy)

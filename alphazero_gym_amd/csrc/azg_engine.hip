@@ -84,6 +84,8 @@ struct KParams {
     double* edge_W;          // [B][R]      edge cumulative return
     float* action;           // [B][R]      continuous: edge action
     float* prior;            // [B][R]      discrete: edge prior
+    float* gmm;              // [B][R][15]  continuous mixture head: mu[5] | sigma[5] | cumulative mixture probability[5]
+    int ncomp;               // C (0: squashed Normal)
     unsigned short* child;   // [B][R][Kp]  continuous: child record ids of a node, in creation order
     int* n_rec;              // [B]
     const int* pw_need;      // [n_sims+2]
@@ -352,6 +354,51 @@ __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_
     return total;
 }
 
+#define GMM_MAXC 5
+// DiagonalGMMPolicy head (policies.py:544-560) of one node from the raw network outputs: mu_c, sigma_c = exp(clamp(log_std_c)),
+// cumulative softmax(log_coeff) in component order.  d[15] = mu[5] | sigma[5] | cum[5] (fixed stride so that every index
+// below is a compile-time constant and the arrays stay in registers).
+__device__ __forceinline__ void gmm_params(const f32x4* parts, const float* s_bhead, int tl, int C, float ls_min, float ls_max, float* d) {
+    float mx = head_output(parts, s_bhead, tl, 1 + 2 * C);
+#pragma unroll
+    for (int c = 1; c < GMM_MAXC; ++c)
+        if (c < C) { float v = head_output(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
+    float ex[GMM_MAXC], sum = 0.0f, cum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < GMM_MAXC; ++c) {
+        ex[c] = 0.0f;
+        if (c < C) { ex[c] = azg_expf(head_output(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < GMM_MAXC; ++c) {
+        d[c] = 0.0f; d[GMM_MAXC + c] = 0.0f; d[2 * GMM_MAXC + c] = 2.0f;
+        if (c < C) {
+            float ls = head_output(parts, s_bhead, tl, 1 + C + c);
+            ls = ls < ls_min ? ls_min : (ls > ls_max ? ls_max : ls);
+            d[c] = head_output(parts, s_bhead, tl, 1 + c);
+            d[GMM_MAXC + c] = azg_expf(ls);
+            cum = cum + ex[c] / sum;
+            d[2 * GMM_MAXC + c] = cum;
+        }
+    }
+}
+
+// MixtureSameFamily.sample (policies.py:656-668): component by inverse CDF with the third word of the widening draw
+__device__ __forceinline__ void gmm_pick(const float* d, int C, unsigned long long seed, unsigned gtree, unsigned search, unsigned k,
+                                         float* mu, float* sg) {
+    azg_u32x4 b = azg_draw(seed, gtree, search, k, AZG_STREAM_PW);
+    float u = azg_u01(b.v[2]);
+    float m = 0.0f, s = 0.0f;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < GMM_MAXC; ++i) {
+        bool last = (i == C - 1);
+        if (i < C && !found && (u < d[2 * GMM_MAXC + i] || last)) { m = d[i]; s = d[GMM_MAXC + i]; found = true; }
+    }
+    *mu = m;
+    *sg = s;
+}
+
 // ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
 
 // cross-lane moves inside a 16-lane row (one tree) on the DPP network: no LDS traffic, one VALU op each
@@ -512,7 +559,7 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
     }
 }
 
-template <int ENV, int HP, int NREG, bool TLDS>
+template <int ENV, int HP, int NREG, bool TLDS, bool GMM>
 __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int S = CONT ? 2 : 4;
@@ -644,14 +691,27 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             if (need_eval) {
                 V = head_output(s_parts, s_bhead, tl, 0);
                 if (CONT) {
-                    float mu = head_output(s_parts, s_bhead, tl, 1);
-                    float ls = head_output(s_parts, s_bhead, tl, 2);
-                    ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
-                    float sg = azg_expf(ls);
+                    float mu, sg;
+                    float gd[15];
+                    if constexpr (GMM) {
+                        gmm_params(s_parts, s_bhead, tl, P.ncomp, P.ls_min, P.ls_max, gd);
+                        mu = gd[0]; sg = gd[GMM_MAXC];
+                        float* g = P.gmm + (tb + leaf) * 3 * GMM_MAXC;
+                        if (sub == 0) {
+#pragma unroll
+                            for (int i = 0; i < 3 * GMM_MAXC; ++i) g[i] = gd[i];
+                        }
+                    } else {
+                        mu = head_output(s_parts, s_bhead, tl, 1);
+                        float ls = head_output(s_parts, s_bhead, tl, 2);
+                        ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
+                        sg = azg_expf(ls);
+                    }
                     if (sub == 0) { cold[leaf].V = V; cold[leaf].mu = mu; cold[leaf].sg = sg; }
                     if (sim < 0) {
                         // add_pw_action(root) before the first trace (mcts.py:673)
                         int k = nrec++;
+                        if constexpr (GMM) gmm_pick(gd, P.ncomp, P.seed, gtree, P.search_idx, (unsigned)k, &mu, &sg);
                         float eps = __shfl(eps_c, k - kbase, 16);
                         float a = P.bound_f * azg_tanhf(mu + sg * eps);
                         if (sub == 0) {
@@ -805,7 +865,15 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     const int K = hp.n_child;
                     chosen = nrec++;
                     float eps = __shfl(eps_c, chosen - kbase, 16);
-                    cact = P.bound_f * azg_tanhf(cp.mu + cp.sg * eps);
+                    float wmu = cp.mu, wsg = cp.sg;
+                    if constexpr (GMM) {
+                        float gd[15];
+                        const float* g = P.gmm + (tb + p) * 3 * GMM_MAXC;
+#pragma unroll
+                        for (int i = 0; i < 3 * GMM_MAXC; ++i) gd[i] = g[i];
+                        gmm_pick(gd, P.ncomp, P.seed, gtree, P.search_idx, (unsigned)chosen, &wmu, &wsg);
+                    }
+                    cact = P.bound_f * azg_tanhf(wmu + wsg * eps);
                     if (sub == 0) {
                         Rec h = make_edge<Rec>((double)cp.V, p);
                         clear_pad(h);
@@ -915,7 +983,11 @@ __global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions
     vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
     nch[tree] = nc;
     root_V[tree] = P.cold[tb].V;
-    if (cont) {
+    if (cont && P.ncomp >= 2) {
+        for (int part = 0; part < 3; ++part)
+            for (int c = 0; c < P.ncomp; ++c)
+                root_dist[(size_t)tree * 3 * P.ncomp + part * P.ncomp + c] = P.gmm[tb * 3 * GMM_MAXC + part * GMM_MAXC + c];
+    } else if (cont) {
         root_dist[(size_t)tree * 2] = P.cold[tb].mu;
         root_dist[(size_t)tree * 2 + 1] = P.cold[tb].sg;
     } else {
@@ -1102,10 +1174,10 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
     return AZG_OK;
 }
 
-template <int ENV, int HP, int NREG, bool TLDS>
-static hipError_t launch_t(azg_engine* e) {
+template <int ENV, int HP, int NREG, bool TLDS, bool GMM>
+static hipError_t launch_g(azg_engine* e) {
     dim3 grid((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG), block(256);
-    auto kern = search_kernel<ENV, HP, NREG, TLDS>;
+    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM>;
     if (e->dyn_lds > 48 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dyn_lds);
         if (rc != hipSuccess) return rc;
@@ -1128,6 +1200,14 @@ static void plan_lds(azg_engine* e) {
     if (force && force[0] == '1') fits = false;
     e->tree_lds = fits ? 1 : 0;
     e->dyn_lds = fits ? off + per * TREES_PER_WG : off;
+}
+
+template <int ENV, int HP, int NREG, bool TLDS>
+static hipError_t launch_t(azg_engine* e) {
+    if constexpr (ENV != AZG_ENV_CARTPOLE) {
+        if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true>(e);
+    }
+    return launch_g<ENV, HP, NREG, TLDS, false>(e);
 }
 
 template <int ENV, int HP, int NREG>
@@ -1288,7 +1368,12 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
     if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
     if (d->in_dim != e->S_obs) return fail(e, AZG_E_INVALID, "in_dim does not match the env observation");
-    if (d->n_dist != e->nd) return fail(e, AZG_E_INVALID, "n_dist does not match the engine mode");
+    int ncomp = 0;
+    if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
+        ncomp = d->num_components >= 2 ? d->num_components : 0;
+        if (ncomp > 5) return fail(e, AZG_E_UNSUPPORTED, "at most 5 mixture components");
+        if (d->n_dist != (ncomp ? 3 * ncomp : 2)) return fail(e, AZG_E_INVALID, "n_dist does not match num_components");
+    } else if (d->n_dist != e->nd) return fail(e, AZG_E_INVALID, "n_dist does not match the engine mode");
     if (1 + d->n_dist > 16) return fail(e, AZG_E_UNSUPPORTED, "at most 15 distribution outputs");
     size_t need = 0;
     int k = d->in_dim, hmax = 0;
@@ -1382,6 +1467,14 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     HIPCHK(e, hipMemcpy(dbh, bh.data(), 16 * 4, hipMemcpyHostToDevice));
     e->P.Whead = (const f32x4*)dWh;
     e->P.bhead = dbh;
+    if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
+        // per-node mixture cache and the root-distribution staging buffer are sized by n_dist (the weight set owns them)
+        float* g = nullptr;
+        if (ncomp) { if (dalloc(e, &g, (size_t)e->cfg.n_trees * e->R * 3 * GMM_MAXC, e->weight_allocs)) return AZG_E_DEVICE; }
+        float* rd = nullptr;
+        if (dalloc(e, &rd, (size_t)e->cfg.n_trees * d->n_dist, e->weight_allocs)) return AZG_E_DEVICE;
+        e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
+    }
     e->HP = HP; e->n_hidden = d->n_hidden; e->n_out = n_out; e->act = d->activation;
     e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
     // hidden->hidden layers that fit the register file stay there for the whole search

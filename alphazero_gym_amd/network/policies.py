@@ -2,8 +2,9 @@
 and inference methods (alphazero/network/policies.py).  The search itself never calls these modules: the engine
 reads their weights (alphazero_gym_amd._capi.policy_blob) and evaluates the MLP on the GPU's matrix cores.
 
-Supported: DiscretePolicy (policies.py:163-352) and DiagonalNormalPolicy (policies.py:355-499).  The GMM and Beta
-heads (policies.py:502-803) are not built yet."""
+Supported: DiscretePolicy (policies.py:163-352), DiagonalNormalPolicy (policies.py:355-499) and DiagonalGMMPolicy
+(policies.py:502-669, the reference's default continuous head).  The Beta head (policies.py:672-803) is not built (the
+reference marks it as not working, README.md:21-22)."""
 from typing import List, Optional
 
 import numpy as np
@@ -132,6 +133,71 @@ class DiagonalNormalPolicy(_PolicyBase):
         return self._dist(mu, sigma).sample().detach().cpu().numpy()
 
 
+class DiagonalGMMPolicy(_PolicyBase):
+    """Mixture of `num_components` squashed Normals per state (policies.py:502-669).  dist_head layout:
+    [mu_0..mu_C-1 | log_std_0..log_std_C-1 | log_coeff_0..log_coeff_C-1] for action_dim == 1."""
+
+    policy_type = "DiagonalGMM"
+
+    def __init__(self, representation_dim: int, action_dim: int, action_bound: Optional[float], num_components: int,
+                 hidden_dimensions: List[int], nonlinearity: str, layernorm: bool = False, log_param_min: float = -5,
+                 log_param_max: float = 2):
+        super().__init__()
+        self._setup(representation_dim, action_dim, hidden_dimensions, nonlinearity, layernorm)
+        if action_dim != 1:
+            raise NotImplementedError("the engine implements one-dimensional actions")
+        self.action_bound = action_bound
+        self.log_param_min = log_param_min
+        self.log_param_max = log_param_max
+        self.num_components = num_components
+        self.dist_head = nn.Linear(self.hidden_dimensions[-1], num_components * (2 * action_dim + 1))
+
+    @property
+    def bounds(self) -> np.ndarray:
+        if self.action_bound is None:
+            return np.array([-np.inf, np.inf], dtype=np.float32)
+        return np.array([-self.action_bound, self.action_bound], dtype=np.float32)
+
+    def forward(self, x):
+        h = self.trunk(x)
+        V_hat = self.value_head(h)
+        params = self.dist_head(h)
+        C_ = self.num_components
+        dist_params = params[..., :C_ * 2 * self.action_dim].reshape(h.shape[0], -1)
+        log_coeff = params[..., -C_:]
+        mu, log_std = dist_params.chunk(2, dim=-1)
+        log_std = torch.clamp(log_std, min=self.log_param_min, max=self.log_param_max)
+        return mu, log_std.exp(), log_coeff, V_hat
+
+    def _component(self, mu, sigma):
+        if self.action_bound:
+            return SquashedNormal(mu, sigma, self.action_bound)
+        return torch.distributions.Normal(mu, sigma)
+
+    def get_train_data(self, states, actions):
+        """Mixture log-probs [B, K] = logsumexp_c(log_softmax(log_coeff)_c + log p_c(a)), entropy estimate [B], V_hat [B, 1]
+        (policies.py:633-654; the squashed component's log|det J| sees x.shape[-1] == num_components there)."""
+        mu, sigma, log_coeff, V_hat = self(states)
+        K = actions.shape[-1]
+        mu = mu.unsqueeze(dim=1).expand((-1, K, -1))
+        sigma = sigma.unsqueeze(dim=1).expand((-1, K, -1))
+        log_mix = torch.log_softmax(log_coeff, dim=-1).unsqueeze(dim=1).expand((-1, K, -1))
+        comp_lp = self._component(mu, sigma).log_prob(actions.unsqueeze(-1))
+        log_probs = torch.logsumexp(comp_lp + log_mix, dim=-1)
+        return log_probs, -log_probs.mean(dim=-1), V_hat
+
+    @torch.no_grad()
+    def predict_V(self, x) -> np.ndarray:
+        return self.value_head(self.trunk(x)).detach().cpu().numpy()
+
+    @torch.no_grad()
+    def sample_action(self, x) -> np.ndarray:
+        mu, sigma, log_coeff, _ = self(x)
+        comp = torch.distributions.Categorical(logits=log_coeff).sample().unsqueeze(-1)
+        a = self._component(mu, sigma).sample()
+        return torch.gather(a, -1, comp).detach().cpu().numpy()
+
+
 def make_policy(representation_dim: int, action_dim: int, distribution: str, hidden_dimensions: List[int], nonlinearity: str,
                 num_components: Optional[int] = None, num_actions: Optional[int] = None, action_bound: Optional[float] = None,
                 layernorm: bool = False, log_param_min: float = -5, log_param_max: float = 2):
@@ -143,6 +209,7 @@ def make_policy(representation_dim: int, action_dim: int, distribution: str, hid
         raise NotImplementedError("GeneralizedBetaPolicy is not built (the reference marks it as not working, README.md:21-22)")
     assert num_components
     if num_components > 1:
-        raise NotImplementedError("DiagonalGMMPolicy (num_components > 1) is not built yet; use num_components=1 (squashed Normal)")
+        return DiagonalGMMPolicy(representation_dim, action_dim, action_bound, num_components, hidden_dimensions, nonlinearity, layernorm,
+                                 log_param_min, log_param_max)
     return DiagonalNormalPolicy(representation_dim, action_dim, action_bound, hidden_dimensions, nonlinearity, layernorm,
                                 log_param_min, log_param_max)

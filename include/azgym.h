@@ -64,8 +64,8 @@ typedef struct azg_config {
 } azg_config;
 
 /* Policy/value MLP: trunk of n_hidden Linear+activation layers, value head Linear(H,1), distribution head
- * Linear(H, n_dist) with n_dist = num_actions (DiscretePolicy, policies.py:238-259) or 2*action_dim
- * (DiagonalNormalPolicy, policies.py:434).  Weight blob = torch state_dict order and layout:
+ * Linear(H, n_dist) with n_dist = num_actions (DiscretePolicy, policies.py:238-259), 2*action_dim
+ * (DiagonalNormalPolicy, policies.py:434) or num_components*(2*action_dim+1) (DiagonalGMMPolicy, policies.py:541-542).  Weight blob = torch state_dict order and layout:
  * for each trunk layer W[out][in] then b[out]; value_head W[1][H], b[1]; dist_head W[n_dist][H], b[n_dist]. */
 typedef struct azg_mlp_desc {
     int32_t struct_size;
@@ -76,6 +76,9 @@ typedef struct azg_mlp_desc {
     int32_t activation;    /* AZG_ACT_* */
     float log_std_min;     /* clamp of log_std (policies.py:456-460); continuous only */
     float log_std_max;
+    int32_t num_components; /* continuous only: 0/1 = squashed Normal (n_dist = 2); C >= 2 = Gaussian mixture,
+                             * DiagonalGMMPolicy (policies.py:502-669), n_dist = 3C laid out [mu_0..mu_C-1, log_std_0.., log_coeff_0..] */
+    int32_t reserved1;
 } azg_mlp_desc;
 
 typedef struct azg_engine azg_engine;

@@ -46,6 +46,7 @@ typedef struct {
     int n_out;                 /* 1 + n_dist */
     int act;
     float ls_min, ls_max;
+    int ncomp;                 /* mixture components (0: squashed Normal) */
     float* W[AZG_MAX_HIDDEN_LAYERS];  /* [hidp][kp] zero padded; kp = in_dim (layer 0) or hidp[l-1] */
     float* b[AZG_MAX_HIDDEN_LAYERS];
     float* Wh;                 /* [n_out][hidp_last] */
@@ -221,14 +222,28 @@ static void evaluate_obs(const azg_engine* e, const float* obs, float* V, float*
     float out[1 + 64];
     mlp_forward(&e->mlp, obs, out);
     *V = out[0];
-    if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
-        int ad = e->n_dist / 2;
-        for (int i = 0; i < ad; ++i) {
-            float ls = out[1 + ad + i];
+    if (e->cfg.mode == AZG_MODE_CONTINUOUS && e->mlp.ncomp >= 2) {
+        /* DiagonalGMMPolicy.forward (policies.py:544-560): [mu_c], [log_std_c], [log_coeff_c]; cached as mu, sigma and the
+         * cumulative mixture probabilities (softmax of log_coeff, summed in component order) */
+        int C = e->mlp.ncomp;
+        float mx = out[1 + 2 * C];
+        for (int c = 1; c < C; ++c) mx = out[1 + 2 * C + c] > mx ? out[1 + 2 * C + c] : mx;
+        float ex[8], sum = 0.0f, cum = 0.0f;
+        for (int c = 0; c < C; ++c) { ex[c] = azg_expf(out[1 + 2 * C + c] - mx); sum = sum + ex[c]; }
+        for (int c = 0; c < C; ++c) {
+            float ls = out[1 + C + c];
             ls = ls < e->mlp.ls_min ? e->mlp.ls_min : (ls > e->mlp.ls_max ? e->mlp.ls_max : ls);
-            dist[i] = out[1 + i];
-            dist[ad + i] = azg_expf(ls);
+            dist[c] = out[1 + c];
+            dist[C + c] = azg_expf(ls);
+            cum = cum + ex[c] / sum;
+            dist[2 * C + c] = cum;
         }
+    } else if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
+        /* DiagonalNormalPolicy.forward (policies.py:436-464) */
+        float ls = out[2];
+        ls = ls < e->mlp.ls_min ? e->mlp.ls_min : (ls > e->mlp.ls_max ? e->mlp.ls_max : ls);
+        dist[0] = out[1];
+        dist[1] = azg_expf(ls);
     } else {
         int A = e->n_dist;
         float mx = out[1];
@@ -313,7 +328,17 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
     if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
     if (d->in_dim != e->S_obs) return fail(e, AZG_E_INVALID, "in_dim does not match the env observation");
-    if (d->n_dist != e->n_dist) return fail(e, AZG_E_INVALID, "n_dist does not match the engine mode");
+    if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
+        int C = d->num_components >= 2 ? d->num_components : 0;
+        if (C > 5) return fail(e, AZG_E_UNSUPPORTED, "at most 5 mixture components");
+        if (d->n_dist != (C ? 3 * C : 2)) return fail(e, AZG_E_INVALID, "n_dist does not match num_components");
+        if (d->n_dist != e->n_dist) {
+            /* the per-node distribution cache is sized by n_dist */
+            for (int i = 0; i < e->cfg.n_trees; ++i) { free(e->trees[i].dist); e->trees[i].dist = (float*)calloc((size_t)e->R * d->n_dist, 4); }
+            e->n_dist = d->n_dist;
+        }
+        e->mlp.ncomp = C;
+    } else if (d->n_dist != e->n_dist) return fail(e, AZG_E_INVALID, "n_dist does not match the engine mode");
     size_t need = 0;
     int k = d->in_dim;
     for (int l = 0; l < d->n_hidden; ++l) {
@@ -405,8 +430,17 @@ static int widen(ctx_t* c, int p) {
     const azg_engine* e = c->e;
     tree_t* t = c->t;
     int k = t->n_rec++;
-    float mu = t->dist[(size_t)p * 2], sigma = t->dist[(size_t)p * 2 + 1];
+    const float* d = t->dist + (size_t)p * e->n_dist;
+    float mu = d[0], sigma = d[1];
     float eps = azg_normal(e->cfg.seed, c->gtree, c->search, (uint32_t)k);
+    if (e->mlp.ncomp >= 2) {
+        /* MixtureSameFamily.sample (policies.py:656-668): pick a component by inverse CDF, then sample it */
+        int C = e->mlp.ncomp, comp = C - 1;
+        azg_u32x4 b = azg_draw(e->cfg.seed, c->gtree, c->search, (uint32_t)k, AZG_STREAM_PW);
+        float u = azg_u01(b.v[2]);
+        for (int i = 0; i < C; ++i) if (u < d[2 * C + i]) { comp = i; break; }
+        mu = d[comp]; sigma = d[C + comp];
+    }
     float z = mu + sigma * eps;
     float a = (float)e->cfg.action_bound * azg_tanhf(z);
     t->parent[k] = p; t->edge_n[k] = 0; t->edge_W[k] = 0.0; t->edge_Q[k] = (double)t->node_V[p];

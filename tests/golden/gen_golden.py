@@ -318,6 +318,22 @@ def run_t2():
         out[f"{name}_V"] = pol.predict_V(x).reshape(-1)
         out[f"{name}_mu"] = mu.numpy().reshape(-1)
         out[f"{name}_sigma"] = sigma.numpy().reshape(-1)
+    # the reference's default continuous head: 2-component Gaussian mixture (config/policy/ContinuousPolicy.yaml:7)
+    for name, hidden, nc in (("g128x3", [128, 128, 128], 2), ("g64c3", [64, 64], 3)):
+        blob = O.make_weights(35, 3, hidden, 3 * nc)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                          num_components=nc, action_bound=2.0)
+        set_policy_weights(pol, blob, 3, hidden, 3 * nc)
+        th = rng.uniform(-np.pi, np.pi, 64); thd = rng.uniform(-8, 8, 64)
+        obs = np.stack([np.cos(th), np.sin(th), thd], 1).astype(np.float32)
+        with torch.no_grad():
+            pol.eval()
+            mu, sigma, log_coeff, V = pol(torch.from_numpy(obs))
+        out[f"{name}_obs"] = obs
+        out[f"{name}_V"] = V.numpy().reshape(-1)
+        out[f"{name}_mu"] = mu.numpy()
+        out[f"{name}_sigma"] = sigma.numpy()
+        out[f"{name}_mix"] = torch.softmax(log_coeff, -1).numpy()
     for name, hidden, act in (("d128", [128, 128], "relu"), ("d64elu", [64, 64], "elu")):
         blob = O.make_weights(34, 4, hidden, 2)
         pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity=act,
@@ -464,6 +480,13 @@ def run_t5():
     lt = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0, device="cpu")
     d = lt(log_probs=lp, counts=torch.from_numpy(counts), entropy=ent, V=torch.from_numpy(V), V_hat=vh)
     out["c_a0c_tuned"] = np.array([float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss")] + [float(lt.alpha)])
+    # mixture head
+    blob = O.make_weights(23, 3, hidden, 6)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                      num_components=2, action_bound=2.0)
+    set_policy_weights(pol, blob, 3, hidden, 6)
+    lp, ent, vh = pol.get_train_data(torch.from_numpy(out["c_states"]), torch.from_numpy(out["c_actions"]))
+    out.update(g_log_probs=lp.detach().numpy(), g_entropy=ent.detach().numpy(), g_V_hat=vh.detach().numpy())
     # discrete
     blob = O.make_weights(22, 4, hidden, 2)
     pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu", num_actions=2)

@@ -164,6 +164,13 @@ def test_training_step_matches_reference_losses():
     d = lt(log_probs=lp, counts=torch.from_numpy(z["c_counts"]), entropy=ent, V=torch.from_numpy(z["c_V"]), V_hat=vh)
     got = [float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss")] + [float(lt.alpha)]
     np.testing.assert_allclose(got, z["c_a0c_tuned"], rtol=1e-5)
+    gm = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                     num_components=2, action_bound=2.0)
+    load_blob(gm, O.make_weights(23, 3, [64, 64], 6))
+    lp, ent, vh = gm.get_train_data(torch.from_numpy(z["c_states"]), torch.from_numpy(z["c_actions"]))
+    np.testing.assert_allclose(lp.detach().numpy(), z["g_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ent.detach().numpy(), z["g_entropy"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(vh.detach().numpy(), z["g_V_hat"], rtol=1e-5, atol=1e-5)
     pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=2)
     load_blob(pol, O.make_weights(22, 4, [64, 64], 2))
     lp, ent, vh = pol.get_train_data(torch.from_numpy(z["d_states"]), torch.from_numpy(z["d_actions"]))
@@ -202,3 +209,27 @@ def test_reference_policy_objects_are_accepted_by_policy_blob():
     desc, blob = _capi.policy_blob(pol)
     assert desc.n_hidden == 2 and list(desc.hidden)[:2] == [32, 48] and desc.n_dist == 2 and desc.activation == _capi.ACT["elu"]
     assert blob.size == 3 * 32 + 32 + 32 * 48 + 48 + 48 + 1 + 2 * 48 + 2
+
+
+def test_gmm_policy_runs_through_the_facade(backend):
+    """The reference's default continuous policy (2-component mixture, 3x128 ELU) searched by the engine: sampled actions
+    come from one of the components of the root's mixture, and the mixture sampling statistics follow the weights."""
+    torch.manual_seed(1)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[128, 128, 128], nonlinearity="elu",
+                      num_components=2, action_bound=2.0)
+    m = MCTSContinuous(model=pol, n_rollouts=64, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0, V_target_policy="off_policy",
+                       device="cpu", root_state=None)
+    envs = [PendulumEnv(state=[0.3 * i - 2.0, 0.1 * i - 0.5]) for i in range(12)]
+    m.search(envs)
+    rows = m.return_results("max_visit")
+    V, dist = m._batched.engine.root_eval()
+    assert dist.shape == (12, 6)
+    with torch.no_grad():
+        obs = torch.from_numpy(np.stack([e._get_obs() for e in envs])).float()
+        mu, sigma, log_coeff, Vt = pol(obs)
+    np.testing.assert_allclose(V, Vt.numpy().reshape(-1), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(dist[:, :2], mu.numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(dist[:, 2:4], sigma.numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(dist[:, 4:], np.cumsum(torch.softmax(log_coeff, -1).numpy(), 1), atol=1e-5, rtol=1e-5)
+    for (s, a, c, q, v) in rows:
+        assert c.sum() == 64 and len(a) == 8 and (np.abs(a) <= 2.0).all()

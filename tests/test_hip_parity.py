@@ -94,6 +94,9 @@ CONFIGS = [
     (0, 0, [128, 128], "relu", 100, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
     (0, 0, [64, 64], "elu", 60, dict(c_uct=20.0, gamma=0.95, epsilon=0.1, num_actions=2, v_target="on_policy")),
     (0, 0, [256, 256], "relu", 80, dict(c_uct=5.0, gamma=0.99, num_actions=2)),
+    # Gaussian-mixture policy heads (the reference's default continuous config: 2 components, 3x128 ELU)
+    (2, 1, [128, 128, 128], "elu", 60, dict(c_uct=0.05, gamma=1.0, _ncomp=2)),
+    (1, 1, [64, 64], "elu", 40, dict(c_uct=0.2, gamma=0.95, c_pw=1.5, kappa=0.6, _ncomp=3)),
     # wide MLPs (BASELINE config E is 4x1024): weights streamed from L2, activation buffers up to 128 KB of LDS
     (2, 1, [512, 512], "elu", 30, dict(c_uct=0.05, gamma=1.0)),
     (2, 1, [1024, 1024, 1024, 1024], "elu", 12, dict(c_uct=0.05, gamma=1.0)),
@@ -111,14 +114,16 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     Variants force the fallback code paths: weights streamed from L2 instead of registers, trees in global memory
     instead of LDS."""
     env, mode, hidden, act, n_sims, extra = cfg
+    extra = dict(extra)
+    ncomp = extra.pop("_ncomp", 0)
     if variant == "stream_weights":
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
     if variant == "global_tree":
         monkeypatch.setenv("AZG_FORCE_GLOBAL_TREE", "1")
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
-    in_dim, n_dist = (3, 2) if mode == 1 else (4, 2)
-    desc = _capi.make_desc(in_dim, hidden, n_dist, act)
+    in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else (4, 2)
+    desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp)
     blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
     o = O.OracleEngine(**kw)
     roots = o.synthetic_roots()

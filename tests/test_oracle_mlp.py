@@ -29,6 +29,15 @@ def test_mlp_matches_torch_policies():
         np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 0], z[f"{name}_mu"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 1], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
+    # Gaussian-mixture head (DiagonalGMMPolicy, the reference's default continuous policy)
+    for name, hidden, nc in (("g128x3", [128, 128, 128], 2), ("g64c3", [64, 64], 3)):
+        e = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
+        e.set_weights(_capi.make_desc(3, hidden, 3 * nc, "elu", num_components=nc), O.make_weights(35, 3, hidden, 3 * nc))
+        v, d, _ = e.mlp_eval(z[f"{name}_obs"])
+        np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, :nc], z[f"{name}_mu"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, nc:2 * nc], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 2 * nc:], np.cumsum(z[f"{name}_mix"], 1), atol=TOL, rtol=TOL)
     for name, hidden, act in (("d128", [128, 128], "relu"), ("d64elu", [64, 64], "elu")):
         e = _eng(0, hidden, act)
         v, d, _ = e.mlp_eval(z[f"{name}_obs"])
