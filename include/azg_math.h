@@ -168,14 +168,16 @@ AZG_HD void azg_sincos(double x, double* sn, double* cs) {
     *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
 
-/* Python/NumPy float `x % y` for y > 0 and |x/y| < 2^20: exact, result in [0, y). */
-AZG_HD double azg_pymod(double x, double y) {
-    double q = x / y;
-    double qt = (double)(long long)q; /* trunc */
+/* Python/NumPy float `x % y` for y > 0 and |x/y| < 2^20: exact, result in [0, y).  inv_y = 1/y (any rounding): the
+ * quotient estimate trunc(x * inv_y) may be off by one, which the sign of the first remainder reveals; the second fma
+ * then computes x - q*y for the true floor quotient, which is exactly representable (the fmod property). */
+AZG_HD double azg_pymod(double x, double y, double inv_y) {
+    double qt = (double)(long long)(x * inv_y); /* trunc */
+    double r0 = AZG_FMA(-qt, y, x);
+    double adj = r0 < 0.0 ? -1.0 : (r0 >= y ? 1.0 : 0.0);
+    qt = qt + adj;
     double r = AZG_FMA(-qt, y, x);
-    if (r < 0.0) r = r + y;
-    if (r >= y) r = r - y;
-    if (r < 0.0) r = r + y;
+    if (r < 0.0) r = r + y;   /* x < 0 with trunc instead of floor: one more period (exact: both terms are multiples of ulp) */
     return r;
 }
 

@@ -142,7 +142,7 @@ static void pendulum_step(int v1, const double* s, float action, double* o, doub
     double th = s[0], thdot = s[1];
     float uc = action < -max_torque ? -max_torque : (action > max_torque ? max_torque : action);
     double u = (double)uc;
-    double an = azg_pymod(th + pi, 2.0 * pi) - pi;
+    double an = azg_pymod(th + pi, 2.0 * pi, 0.15915494309189535) - pi;
     double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
     double newth, newthdot, sn, cs;
     if (v1) {
@@ -806,7 +806,7 @@ int azo_math_eval(int fn_id, const double* in, double* out, size_t n) {
             case 4: out[i] = (double)azg_cos2pif((float)x); break;
             case 5: azg_sincos(x, &s, &c); out[i] = s; break;
             case 6: azg_sincos(x, &s, &c); out[i] = c; break;
-            case 7: out[i] = azg_pymod(x, 2.0 * 3.141592653589793); break;
+            case 7: out[i] = azg_pymod(x, 2.0 * 3.141592653589793, 0.15915494309189535); break;
             case 8: out[i] = (double)azg_normal(34u, (uint32_t)x, 0u, (uint32_t)(x * 7.0)); break;
             case 9: out[i] = (double)((float)x / 3.0f); break;
             case 10: out[i] = (double)__builtin_sqrtf((float)x); break;
