@@ -1,0 +1,182 @@
+// aux_kernels.cuh -- result gathering, the device-resident self-play step, and the math / MFMA self tests.
+#pragma once
+#include "records.h"
+#include "env.cuh"
+
+// ------------------------------------------------------------------------------------------------ result gathering
+
+// MCTS.return_results (mcts.py:269-307): one thread per tree, from the published (global) trees
+__global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt, int* nch,
+                               int* child_n, double* child_state, float* root_V, float* root_dist) {
+    int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= P.B) return;
+    size_t tb = (size_t)tree * P.R;
+    const RecL* hot = P.hot + tb;
+    const unsigned short* child = P.child + tb * P.Kp;
+    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
+    const RecL root = hot[0];
+    int nc = root.n_child;
+    long tot = 0;
+    for (int a = 0; a < nc; ++a) tot += hot[cont ? child[a] : root.first + a].edge_n;
+    double qmax = 0.0, onp = 0.0;
+    for (int a = 0; a < Kmax; ++a) {
+        int k = a < nc ? (cont ? (int)child[a] : (int)root.first + a) : -1;
+        RecL h = hot[k >= 0 ? k : 0];
+        actions[(size_t)tree * Kmax + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
+        counts[(size_t)tree * Kmax + a] = k >= 0 ? h.edge_n : 0;
+        Q[(size_t)tree * Kmax + a] = k >= 0 ? h.Q : 0.0;
+        bool ex = k >= 0 && (h.flags & FLAG_EXPANDED);
+        child_n[(size_t)tree * Kmax + a] = ex ? h.node_n : -1;
+        for (int s = 0; s < P.S; ++s) child_state[((size_t)tree * Kmax + a) * P.S + s] = ex ? P.cold[tb + k].s[s] : 0.0;
+        if (k >= 0) {
+            if (a == 0 || h.Q > qmax) qmax = h.Q;
+            if (!cont) onp += ((double)h.edge_n / (double)tot) * h.Q;
+        }
+    }
+    if (cont) {
+        // reference quirk (mcts.py:111 with Q of shape (K,1)): the K x K outer product is summed
+        for (int a = 0; a < nc; ++a)
+            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+    }
+    vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
+    nch[tree] = nc;
+    root_V[tree] = P.cold[tb].V;
+    if (cont && P.ncomp >= 2) {
+        for (int part = 0; part < 3; ++part)
+            for (int c = 0; c < P.ncomp; ++c)
+                root_dist[(size_t)tree * 3 * P.ncomp + part * P.ncomp + c] = P.gmm[tb * 3 * GMM_MAXC + part * GMM_MAXC + c];
+    } else if (cont) {
+        root_dist[(size_t)tree * 2] = P.cold[tb].mu;
+        root_dist[(size_t)tree * 2 + 1] = P.cold[tb].sg;
+    } else {
+        for (int d = 0; d < P.nd; ++d) root_dist[(size_t)tree * P.nd + d] = P.prior[tb + root.first + d];
+    }
+}
+
+// One self-play step after a search, one thread per game: replay row, the agent's final action rule, the real env step,
+// episode bookkeeping and the next search's root (the CPU oracle restates the same arithmetic for the parity tests).
+struct SelfPlay {
+    int max_len, deterministic;
+    unsigned step_idx;
+    int* t; int* episode; int* fcnt;
+    double* ret; double* fsum;
+    float* rows;          // this step's block [B][row_len]
+    double* roots; int* carry;
+};
+
+__global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
+    int tree = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tree >= P.B) return;
+    const size_t tb = (size_t)tree * P.R;
+    const RecL* hot = P.hot + tb;
+    const unsigned short* child = P.child + tb * P.Kp;
+    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
+    const unsigned gtree = (unsigned)(P.tree_base + tree);
+    const int S = P.S, K = Kmax, RL = S_obs + 3 * Kmax + 1;
+    double root[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < S; ++k) root[k] = sp.roots[(size_t)tree * S + k];
+    float* row = sp.rows + (size_t)tree * RL;
+    const RecL r0 = hot[0];
+    const int nc = r0.n_child;
+    float obs[4];
+    double sn;
+    if (env_id == AZG_ENV_CARTPOLE) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
+    double qmax = 0.0, onp = 0.0;
+    long tot = 0;
+    int cmax = 0, amax = 0;
+    for (int a = 0; a < nc; ++a) tot += hot[cont ? (int)child[a] : (int)r0.first + a].edge_n;
+    for (int a = 0; a < K; ++a) {
+        int k = a < nc ? (cont ? (int)child[a] : (int)r0.first + a) : -1;
+        RecL h = hot[k >= 0 ? k : 0];
+        row[S_obs + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
+        row[S_obs + K + a] = k >= 0 ? (float)h.edge_n : 0.0f;
+        row[S_obs + 2 * K + a] = k >= 0 ? (float)h.Q : 0.0f;
+        if (k >= 0) {
+            if (a == 0 || h.Q > qmax) qmax = h.Q;
+            if (!cont) onp += ((double)h.edge_n / (double)tot) * h.Q;
+            if (a == 0 || h.edge_n > cmax) { cmax = h.edge_n; amax = a; }
+        }
+    }
+    if (cont)
+        for (int a = 0; a < nc; ++a)
+            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+    row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
+    int pick = amax;
+    if (!cont && !sp.deterministic) {
+        azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+        double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+        double sum = 0.0;
+        for (int a = 0; a < nc; ++a) sum = sum + (double)hot[(int)r0.first + a].edge_n / (double)cmax;
+        double cum = 0.0;
+        pick = nc - 1;
+        for (int a = 0; a < nc; ++a) {
+            cum = cum + ((double)hot[(int)r0.first + a].edge_n / (double)cmax) / sum;
+            if (u < cum) { pick = a; break; }
+        }
+    }
+    const int krec = cont ? (int)child[pick] : (int)r0.first + pick;
+    double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
+    int done;
+    if (env_id == AZG_ENV_CARTPOLE) {
+        cartpole_step(root, pick, ns, &r, &done);
+    } else {
+        double s1, c1;
+        azg_sincos(root[0], &s1, &c1);
+        pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, s1, P.action[tb + krec], ns, &r, &done);
+    }
+    double ret = sp.ret[tree] + r;
+    int t = sp.t[tree] + 1;
+    if (done || t >= sp.max_len) {
+        sp.fsum[tree] = sp.fsum[tree] + ret;
+        sp.fcnt[tree] += 1;
+        ret = 0.0;
+        t = 0;
+        int ep = sp.episode[tree] + 1;
+        sp.episode[tree] = ep;
+        azg_reset_state(P.seed, gtree, (unsigned)ep, env_id == AZG_ENV_CARTPOLE, ns);
+        sp.carry[tree] = 0;
+    } else {
+        RecL hk = hot[krec];
+        sp.carry[tree] = (!cont && (hk.flags & FLAG_EXPANDED)) ? hk.node_n : 0;
+    }
+    sp.ret[tree] = ret;
+    sp.t[tree] = t;
+    for (int k = 0; k < S; ++k) sp.roots[(size_t)tree * S + k] = ns[k];
+}
+
+__global__ void math_selftest_kernel(int fn_id, const double* in, double* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = in[i], s, c;
+    switch (fn_id) {
+        case 0: out[i] = (double)azg_expf((float)x); break;
+        case 1: out[i] = (double)azg_expm1f((float)x); break;
+        case 2: out[i] = (double)azg_tanhf((float)x); break;
+        case 3: out[i] = (double)azg_logf((float)x); break;
+        case 4: out[i] = (double)azg_cos2pif((float)x); break;
+        case 5: azg_sincos(x, &s, &c); out[i] = s; break;
+        case 6: azg_sincos(x, &s, &c); out[i] = c; break;
+        case 7: out[i] = azg_pymod(x, 2.0 * 3.141592653589793, 0.15915494309189535); break;
+        case 8: out[i] = (double)azg_normal(34u, (uint32_t)x, 0u, (uint32_t)(x * 7.0)); break;
+        case 9: out[i] = (double)((float)x / 3.0f); break;
+        case 10: out[i] = (double)__builtin_sqrtf((float)x); break;
+        case 11: out[i] = x / 3.0; break;
+        default: out[i] = 0.0;
+    }
+}
+
+// fn_id 100: one 16x16x4 MFMA chain over n/… ; in = [a0..a(K-1), b0..b(K-1), c], out[0] = D[0][0]; probes the accumulation order
+__global__ void mfma_probe_kernel(const double* in, double* out, int K) {
+    int lane = threadIdx.x;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float c = (float)in[2 * K];
+    acc.x = acc.y = acc.z = acc.w = c;
+    for (int s = 0; s < K / 4; ++s) {
+        int k = 4 * s + (lane >> 4);
+        float a = (float)in[k];
+        float b = (float)in[K + k];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    if (lane == 0) out[0] = (double)acc.x;
+}

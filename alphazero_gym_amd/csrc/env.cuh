@@ -1,0 +1,66 @@
+// env.cuh -- closed-form CartPole / Pendulum dynamics on the device (float64; operation order = alphazero_gym_amd/envs.py).
+#pragma once
+#include "records.h"
+
+// ------------------------------------------------------------------------------------------------ environments
+
+// observation of a state; Pendulum also returns sin(theta) so that the node can cache it for its children's dynamics
+template <int ENV>
+__device__ __forceinline__ void env_obs(const double* s, float* obs, double* sn_out) {
+    if (ENV == AZG_ENV_CARTPOLE) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
+        *sn_out = 0.0;
+    } else {
+        double sn, cs;
+        azg_sincos(s[0], &sn, &cs);
+        obs[0] = (float)cs; obs[1] = (float)sn; obs[2] = (float)s[1]; obs[3] = 0.0f;
+        *sn_out = sn;
+    }
+}
+
+// gym CartPoleEnv.step (explicit Euler); same operation order as oracle/azg_oracle.c cartpole_step
+__device__ __forceinline__ void cartpole_step(const double* s, int action, double* o, double* reward, int* done) {
+    const double gravity = 9.8, masspole = 0.1, total_mass = 0.1 + 1.0, length = 0.5;
+    const double polemass_length = 0.1 * 0.5, force_mag = 10.0, tau = 0.02;
+    const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
+    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    double force = action == 1 ? force_mag : -force_mag;
+    double sintheta, costheta;
+    azg_sincos(theta, &sintheta, &costheta);
+    double temp = (force + (polemass_length * (theta_dot * theta_dot)) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - (masspole * (costheta * costheta)) / total_mass));
+    double xacc = temp - ((polemass_length * thetaacc) * costheta) / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    o[0] = x; o[1] = x_dot; o[2] = theta; o[3] = theta_dot;
+    *done = (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);
+    *reward = 1.0;
+}
+
+// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node
+__device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {
+    const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
+    const float max_torque = 2.0f;
+    double th = s[0], thdot = s[1];
+    float uc = action < -max_torque ? -max_torque : (action > max_torque ? max_torque : action);
+    double u = (double)uc;
+    double an = azg_pymod(th + pi, 2.0 * pi, 0.15915494309189535) - pi;
+    double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
+    double newth, newthdot, sn, cs;
+    if (v1) {
+        newthdot = thdot + (15.0 * sn_th + 3.0 * u) * dt;
+        newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+        newth = th + newthdot * dt;
+    } else {
+        azg_sincos(th + pi, &sn, &cs);
+        newthdot = thdot + (-15.0 * sn + 3.0 * u) * dt;
+        newth = th + newthdot * dt;
+        newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
+    }
+    o[0] = newth; o[1] = newthdot;
+    *reward = -costs;
+    *done = 0;
+}

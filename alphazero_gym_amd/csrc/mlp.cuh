@@ -1,0 +1,232 @@
+// mlp.cuh -- the policy/value MLP of the 16 leaves of a workgroup on v_mfma_f32_16x16x4_f32 (+ ELU, heads, mixture head).
+#pragma once
+#include "records.h"
+
+// ------------------------------------------------------------------------------------------------ MLP on MFMA
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// azg_expm1f on four values at once: the same operations in the same order per component (bit-identical), written
+// component-parallel so that the four dependent fma chains interleave (and pack into v_pk_fma_f32)
+__device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 x) {
+    // x <= 0 here, so only the lower clamp of azg_expm1f can trigger
+    const f32x4 lo = {-87.0f, -87.0f, -87.0f, -87.0f};
+    f32x4 xc = __builtin_elementwise_max(x, lo);
+    const f32x4 magic = {12582912.0f, 12582912.0f, 12582912.0f, 12582912.0f};
+    const f32x4 l2e = {1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f};
+    const f32x4 ln2h = {0.693145751953125f, 0.693145751953125f, 0.693145751953125f, 0.693145751953125f};
+    const f32x4 ln2l = {1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f};
+    f32x4 kf = __builtin_elementwise_fma(xc, l2e, magic);
+    kf = kf - magic;
+    f32x4 r = __builtin_elementwise_fma(-kf, ln2h, xc);
+    r = __builtin_elementwise_fma(-kf, ln2l, r);
+    f32x4 p = {1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f};
+    const f32x4 c5 = {1.38888888888888894e-3f, 1.38888888888888894e-3f, 1.38888888888888894e-3f, 1.38888888888888894e-3f};
+    const f32x4 c4 = {8.33333333333333322e-3f, 8.33333333333333322e-3f, 8.33333333333333322e-3f, 8.33333333333333322e-3f};
+    const f32x4 c3 = {4.16666666666666644e-2f, 4.16666666666666644e-2f, 4.16666666666666644e-2f, 4.16666666666666644e-2f};
+    const f32x4 c2 = {1.66666666666666657e-1f, 1.66666666666666657e-1f, 1.66666666666666657e-1f, 1.66666666666666657e-1f};
+    const f32x4 half = {0.5f, 0.5f, 0.5f, 0.5f}, one = {1.0f, 1.0f, 1.0f, 1.0f};
+    p = __builtin_elementwise_fma(p, r, c5);
+    p = __builtin_elementwise_fma(p, r, c4);
+    p = __builtin_elementwise_fma(p, r, c3);
+    p = __builtin_elementwise_fma(p, r, c2);
+    p = __builtin_elementwise_fma(p, r, half);
+    f32x4 em1 = __builtin_elementwise_fma(p * r, r, r);
+    i32x4 k = __builtin_convertvector(kf, i32x4);
+    f32x4 sc = (f32x4)((k + 127) << 23);
+    return __builtin_elementwise_fma(sc, em1, sc - one);
+}
+
+// ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(+-0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit
+// for bit (the sign of a zero that v_max/v_min may pick differently from the host's select vanishes in the sum)
+__device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 pos = __builtin_elementwise_max(v, zero);
+    if (act == AZG_ACT_ELU) {
+        f32x4 neg = __builtin_elementwise_min(v, zero);
+        return pos + expm1f4_nonpos(neg);
+    }
+    return pos;
+}
+
+__device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+// Register-resident hidden->hidden weights: wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer.
+template <int HP, int NREG>
+struct WRegs {
+    static constexpr int NTW = HP / 64;
+    static constexpr int S4 = HP / 16;
+    f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
+    f32x4 b[NREG > 0 ? NREG : 1][NTW];
+    f32x4 wh[NTW];   // head weights of this wave's K-chunk
+    float w0[NTW];   // first layer (K <= 4: one k-step per tile)
+    f32x4 b0[NTW];
+};
+
+// The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  Result: parts[4 waves][64 lanes] = every
+// wave's partial head sums (head_output() combines them).  Activations cross waves through the two act buffers
+// (HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in
+// registers until the next layer publishes it, and the last layer's output feeds the head MFMAs directly.
+template <int HP, int NREG>
+__device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
+                                            f32x4* parts, int wave, int lane
+#ifdef AZG_STAMPS
+                                            , unsigned long long* st_acc
+#endif
+                                            ) {
+    STAMP(m0);
+    constexpr int NTW = HP / 64;   // output tiles per wave
+    constexpr int S4 = HP / 16;    // groups of 4 MFMA k-steps over a hidden vector
+    f32x4 h[NTW];                  // this wave's tiles of the latest layer, after the activation
+    // layer 0: K = in_dim <= 4 -> one k-step
+    {
+        float b = obsT[lane];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
+    }
+    f32x4* buf = actA;
+    f32x4* other = actB;
+    // hidden->hidden layers held in registers
+    if (NREG > 0) {
+#pragma unroll
+        for (int l = 0; l < NREG; ++l) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            __syncthreads();
+            STAMP(m1);
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = wr.b[l][i];
+            f32x4 bcur = buf[lane];
+#pragma unroll
+            for (int s4 = 0; s4 < S4; ++s4) {
+                f32x4 bnext = bcur;
+                if (s4 + 1 < S4) bnext = buf[(s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
+                __builtin_amdgcn_sched_barrier(0);                    // keep the ds_read above this block's MFMAs
+                // k-step outer, tile inner: consecutive MFMAs are independent chains (40-cycle dependent latency)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].x, bcur.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].y, bcur.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].z, bcur.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].w, bcur.w, acc[i], 0, 0, 0);
+                bcur = bnext;
+            }
+            STAMP(m2);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
+            STAMP(m2b);
+            if (l == 0) { STAMP_ADD(4, m0, m1); }
+            STAMP_ADD(5, m1, m2);
+            STAMP_ADD(6, m2, m2b);
+            f32x4* t = buf; buf = other; other = t;
+        }
+    } else {
+        // weights streamed from global memory (L2-resident), any number of layers
+        for (int l = 1; l < P.n_hidden; ++l) {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            __syncthreads();
+            const f32x4* W = P.Wl[l - 1];
+            const f32x4* bb = P.bl[l - 1];
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] = bb[(wave * NTW + i) * 64 + lane];
+#pragma unroll 2
+            for (int s4 = 0; s4 < S4; ++s4) {
+                f32x4 b = buf[s4 * 64 + lane];
+                f32x4 a[NTW];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) a[i] = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
+            f32x4* t = buf; buf = other; other = t;
+        }
+    }
+    // heads: wave w sums its quarter of the hidden units (chain from 0) straight from its registers
+    {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            f32x4 a = (NREG > 0) ? wr.wh[i] : P.Whead[(wave * NTW + i) * 64 + lane];
+            acc = mfma4(a, h[i], acc);
+        }
+        parts[wave * 64 + lane] = acc;
+    }
+    __syncthreads();
+}
+
+// network output o of tree tl: bias + the four waves' partial sums, added in wave order (the oracle's summation order)
+__device__ __forceinline__ float head_output(const f32x4* parts, const float* s_bhead, int tl, int o) {
+    float total = s_bhead[o];
+    const int idx = (o >> 2) * 16 + tl;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f32x4 pv = parts[w * 64 + idx];
+        float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
+        total = total + p;
+    }
+    return total;
+}
+
+#define GMM_MAXC 5
+// DiagonalGMMPolicy head (policies.py:544-560) of one node from the raw network outputs: mu_c, sigma_c = exp(clamp(log_std_c)),
+// cumulative softmax(log_coeff) in component order.  d[15] = mu[5] | sigma[5] | cum[5] (fixed stride so that every index
+// below is a compile-time constant and the arrays stay in registers).
+__device__ __forceinline__ void gmm_params(const f32x4* parts, const float* s_bhead, int tl, int C, float ls_min, float ls_max, float* d) {
+    float mx = head_output(parts, s_bhead, tl, 1 + 2 * C);
+#pragma unroll
+    for (int c = 1; c < GMM_MAXC; ++c)
+        if (c < C) { float v = head_output(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
+    float ex[GMM_MAXC], sum = 0.0f, cum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < GMM_MAXC; ++c) {
+        ex[c] = 0.0f;
+        if (c < C) { ex[c] = azg_expf(head_output(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < GMM_MAXC; ++c) {
+        d[c] = 0.0f; d[GMM_MAXC + c] = 0.0f; d[2 * GMM_MAXC + c] = 2.0f;
+        if (c < C) {
+            float ls = head_output(parts, s_bhead, tl, 1 + C + c);
+            ls = ls < ls_min ? ls_min : (ls > ls_max ? ls_max : ls);
+            d[c] = head_output(parts, s_bhead, tl, 1 + c);
+            d[GMM_MAXC + c] = azg_expf(ls);
+            cum = cum + ex[c] / sum;
+            d[2 * GMM_MAXC + c] = cum;
+        }
+    }
+}
+
+// MixtureSameFamily.sample (policies.py:656-668): component by inverse CDF with the third word of the widening draw
+__device__ __forceinline__ void gmm_pick(const float* d, int C, unsigned long long seed, unsigned gtree, unsigned search, unsigned k,
+                                         float* mu, float* sg) {
+    azg_u32x4 b = azg_draw(seed, gtree, search, k, AZG_STREAM_PW);
+    float u = azg_u01(b.v[2]);
+    float m = 0.0f, s = 0.0f;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < GMM_MAXC; ++i) {
+        bool last = (i == C - 1);
+        if (i < C && !found && (u < d[2 * GMM_MAXC + i] || last)) { m = d[i]; s = d[GMM_MAXC + i]; found = true; }
+    }
+    *mu = m;
+    *sg = s;
+}

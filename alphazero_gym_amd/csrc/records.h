@@ -1,0 +1,87 @@
+// records.h -- tree record layouts, kernel parameter block, diagnostic stamp macros (device + host).
+#include <hip/hip_runtime.h>
+#pragma once
+#include "../../include/azg_math.h"
+#include "../../include/azgym.h"
+
+#define FLAG_EXPANDED 1
+#define FLAG_TERMINAL 2
+#define TREES_PER_WG 16
+#define MAX_STREAM_LAYERS 8
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Record j of a tree = edge j + (once expanded) the node that edge leads to; record 0 is the root.
+// "Hot" part: everything selection and the count/Q side of backup touch.  Two encodings:
+//   RecS (16 B) lives in LDS for the whole search when the tree fits (<= 255 records, counts < 65536),
+//   RecL (24 B) lives in global memory (any size); it is also the format trees are published in at the end of a search.
+struct __attribute__((aligned(16))) RecS {
+    double Q;                // edge action value (Q_init = parent V)
+    unsigned short edge_n;   // edge visit count
+    unsigned short node_n;   // node visit count
+    unsigned char parent;    // record of the parent node
+    unsigned char n_child;   // node: number of child edges
+    unsigned char flags;     // FLAG_EXPANDED | FLAG_TERMINAL
+    unsigned char first;     // discrete: record of child edge 0 (children are contiguous)
+};
+struct __attribute__((aligned(8))) RecL {
+    double Q;
+    int edge_n;
+    int node_n;
+    short parent;
+    unsigned short n_child;
+    unsigned short first;
+    unsigned char flags;
+    unsigned char pad;
+};
+static_assert(sizeof(RecS) == 16, "RecS must be 16 bytes");
+static_assert(sizeof(RecL) == 24, "RecL must be 24 bytes");
+
+// "Cold" part of a node (global memory): read once when a child is expanded from it or an action is sampled at it
+struct __attribute__((aligned(16))) Cold {
+    double s[4];   // env state (Pendulum: theta, theta_dot, sin(theta) cached, unused)
+    double r;      // reward on arriving here (already divided by reward_scale in continuous mode)
+    float V;       // value estimate
+    float mu;      // continuous: cached squashed-Normal mean
+    float sg;      //             and standard deviation
+    float pad;
+};
+static_assert(sizeof(Cold) == 64, "Cold must be 64 bytes");
+
+struct KParams {
+    int B, n_sims, R, Kp, A, nd, n_out, n_hidden, act, v1, tree_base, mode;
+    double c_uct, gamma, epsilon, reward_scale;
+    float c_uct_f, gamma_f, bound_f, ls_min, ls_max;
+    unsigned long long seed;
+    unsigned search_idx;
+    int S;                   // env state dim
+    int tab_n;               // entries in sqrt_tab
+    const double* roots;     // [B][S]
+    const int* carry;        // [B]
+    RecL* hot;               // [B][R]      published trees (and working storage when the tree does not fit LDS)
+    Cold* cold;              // [B][R]
+    double* edge_W;          // [B][R]      edge cumulative return
+    float* action;           // [B][R]      continuous: edge action
+    float* prior;            // [B][R]      discrete: edge prior
+    float* gmm;              // [B][R][15]  continuous mixture head: mu[5] | sigma[5] | cumulative mixture probability[5]
+    int ncomp;               // C (0: squashed Normal)
+    unsigned short* child;   // [B][R][Kp]  continuous: child record ids of a node, in creation order
+    int* n_rec;              // [B]
+    const int* pw_need;      // [n_sims+2]
+    const double* sqrt_tab;  // [tab_n]  sqrt(n+1)
+    const float* W0;         // [HP/16][64]
+    const f32x4* b0;         // [HP/16][64]
+    const f32x4* Wl[MAX_STREAM_LAYERS]; // hidden->hidden layer l (1-based index l-1): [HP/16 tiles][HP/16 s4][64]
+    const f32x4* bl[MAX_STREAM_LAYERS]; // [HP/16][64]
+    const f32x4* Whead;      // [HP/16 s4][64]
+    const float* bhead;      // [16]
+    unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
+};
+
+#ifdef AZG_STAMPS
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t0, t1)
+#endif

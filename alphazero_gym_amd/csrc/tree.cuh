@@ -1,0 +1,163 @@
+// tree.cuh -- 16-lane (one DPP row) tree primitives: arg-max, record storage in LDS or global memory, backup.
+#pragma once
+#include "records.h"
+
+// ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
+
+// cross-lane moves inside a 16-lane row (one tree) on the DPP network: no LDS traffic, one VALU op each
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    unsigned long long u = azg_d2u(v);
+    unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)u), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(u >> 32));
+    return azg_u2d(((unsigned long long)hi << 32) | lo);
+}
+#define DPP_QUAD_XOR1 0xB1   // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E   // quad_perm:[2,3,0,1]
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+
+// maximum of u over the row (invalid lanes excluded)
+__device__ __forceinline__ double rowmax16(double u, bool valid) {
+    double m = valid ? u : -__builtin_huge_val();
+    double o;
+    o = dpp_f64<DPP_QUAD_XOR1>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_QUAD_XOR2>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_ROW_ROR4>(m); m = o > m ? o : m;
+    o = dpp_f64<DPP_ROW_ROR8>(m); m = o > m ? o : m;
+    return m;
+}
+__device__ __forceinline__ int rowmin16(int c) {
+    int t;
+    t = dpp_i32<DPP_QUAD_XOR1>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_QUAD_XOR2>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_ROW_ROR4>(c); c = t < c ? t : c;
+    t = dpp_i32<DPP_ROW_ROR8>(c); c = t < c ? t : c;
+    return c;
+}
+// lane index (0..15) of the maximum over the row, lowest lane on ties (the reference breaks ties randomly, helpers.py:46-52)
+__device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
+    double m = rowmax16(u, valid);
+    return rowmin16((valid && u == m) ? sub : 99);
+}
+// same, but returns the payload (< 65536) of the winning lane: no second cross-lane round trip
+__device__ __forceinline__ int argmax16_payload(double u, bool valid, int sub, int payload) {
+    double m = rowmax16(u, valid);
+    return rowmin16((valid && u == m) ? ((sub << 16) | payload) : 0x7fffffff) & 0xffff;
+}
+
+// storage of the hot part of one tree: LDS (RecS, 8-bit ids) or global memory (RecL, 16-bit ids)
+template <bool TLDS> struct TreeStore;
+template <> struct TreeStore<true> {
+    typedef RecS Rec;
+    typedef unsigned char Id;
+    Rec* hot; Id* child; float* prior;
+};
+template <> struct TreeStore<false> {
+    typedef RecL Rec;
+    typedef unsigned short Id;
+    Rec* hot; Id* child; float* prior;
+};
+
+template <typename Rec>
+__device__ __forceinline__ Rec make_edge(double Q, int parent) {
+    Rec h;
+    h.Q = Q; h.edge_n = 0; h.node_n = 0; h.parent = (decltype(h.parent))parent; h.n_child = 0; h.flags = 0; h.first = 0;
+    return h;
+}
+__device__ __forceinline__ void clear_pad(RecS&) {}
+__device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
+
+// MCTS.backprop (mcts.py:260-267), generic part: walks parent links from record j to the root, 16 levels at a time
+// (lane d = d-th record), fetches rewards / W in parallel, chains the discounted return serially (its rounding order
+// is part of the contract), then every lane updates its own record.
+template <bool CONT, bool TLDS>
+__device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int j, float V, int sub,
+                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    while (true) {
+        int mine = 0, cnt = 0, jj = j;
+        bool hit_root = false;
+        Rec mrec = ts.hot[jj];
+#pragma unroll 1
+        for (int d = 0; d < 16; ++d) {
+            Rec rr = ts.hot[jj];
+            if (sub == d) { mine = jj; mrec = rr; }
+            cnt = d + 1;
+            if (jj == 0) { hit_root = true; break; }
+            jj = rr.parent;
+        }
+        const bool is_edge = (sub < cnt) && (mine != 0);
+        double r = 0.0, W = 0.0;
+        if (is_edge) { r = cold[mine].r; W = edge_W[mine]; }
+        double myR = 0.0;
+        const int nedge = hit_root ? cnt - 1 : cnt;
+#pragma unroll 1
+        for (int d = 0; d < nedge; ++d) {
+            double rd = __shfl(r, d, 16);
+            double gR;
+            if (firstlvl) {
+                // continuous: V is a float32 0-d array and gamma a python scalar -> float32 product (NumPy >= 2);
+                // discrete: V is a python float -> float64 product
+                gR = CONT ? (double)(gamma_f * V) : gamma * (double)V;
+                firstlvl = false;
+            } else {
+                gR = gamma * Rv;
+            }
+            Rv = rd + gR;
+            if (sub == d) myR = Rv;
+        }
+        if (sub < cnt) {
+            if (is_edge) {
+                int en = (int)mrec.edge_n + 1;
+                double Wn = W + myR;
+                mrec.Q = Wn / (double)en;
+                mrec.edge_n = (decltype(mrec.edge_n))en;
+                edge_W[mine] = Wn;
+            }
+            if (!(at_leaf && sub == 0)) mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
+            ts.hot[mine] = mrec;
+        }
+        if (hit_root) break;
+        j = jj;
+        at_leaf = false;
+    }
+}
+
+// Backup of a trace whose path the descent left in the lanes: slot (depth & 15) holds the record id, its reward and W
+// (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
+template <bool CONT, bool TLDS>
+__device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
+                                            double gamma, int D, int my_depth, int pid, double pr, double pW) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    const int n0 = D < 16 ? D : 16;
+    double Rv = 0.0, myR = 0.0;
+#pragma unroll 1
+    for (int d = 0; d < n0; ++d) {
+        const int src = (D - d) & 15;
+        double rd = __shfl(pr, src, 16);
+        double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * Rv;
+        Rv = rd + gR;
+        if (sub == src) myR = Rv;
+    }
+    const bool valid = my_depth >= 0 && my_depth > D - 16;
+    int par = 0;
+    if (valid) {
+        Rec rec = ts.hot[pid];
+        par = rec.parent;
+        if (my_depth >= 1) {
+            int en = (int)rec.edge_n + 1;
+            double Wn = pW + myR;
+            rec.Q = Wn / (double)en;
+            rec.edge_n = (decltype(rec.edge_n))en;
+            edge_W[pid] = Wn;
+        }
+        if (my_depth < D) rec.node_n = (decltype(rec.node_n))(rec.node_n + 1);
+        ts.hot[pid] = rec;
+    }
+    if (D >= 16) {
+        int j = __shfl(par, (D - 15) & 15, 16);   // parent of the shallowest record handled above
+        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv);
+    }
+}

@@ -101,6 +101,6 @@ def test_product_package_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "alphazero_gym_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".cuh")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in src and "libazg_oracle" not in src and "azo_" not in src.replace('prefix ``azo_``', ""), f
