@@ -21,7 +21,8 @@ AZG_E_UNSUPPORTED = -5
 ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1 = 0, 1, 2
 MODE_DISCRETE, MODE_CONTINUOUS = 0, 1
 VT = {"off_policy": 0, "on_policy": 1, "greedy": 2}
-ACT = {"relu": 0, "elu": 1}
+ACT = {"relu": 0, "elu": 1, "leakyrelu": 2, "relu6": 3, "silu": 4, "swish": 4, "hardswish": 5}
+_ACT_MODULES = {"ReLU": 0, "ELU": 1, "LeakyReLU": 2, "ReLU6": 3, "SiLU": 4, "Hardswish": 5}
 MAX_HIDDEN = 8
 
 PENDULUM_R_SCALE = 16.2736044  # alphazero/search/mcts.py:20
@@ -129,10 +130,10 @@ def policy_blob(policy):
         name = type(mod).__name__
         if name == "Linear":
             linears.append(mod)
-        elif name in ("ReLU", "ELU"):
-            acts.add(name.lower())
+        elif name in _ACT_MODULES:
+            acts.add(_ACT_MODULES[name])
         else:
-            raise NotImplementedError(f"trunk module {name}: the engine implements Linear + ReLU/ELU trunks only")
+            raise NotImplementedError(f"trunk module {name}: the engine implements Linear + pointwise-activation trunks (no LayerNorm)")
     if len(acts) != 1 or len(linears) != len(hidden):
         raise NotImplementedError("unsupported trunk structure")
     desc = AzgMlpDesc()
@@ -142,7 +143,7 @@ def policy_blob(policy):
     for i, h in enumerate(hidden):
         desc.hidden[i] = h
     desc.n_dist = policy.dist_head.out_features
-    desc.activation = ACT[acts.pop()]
+    desc.activation = acts.pop()
     desc.log_std_min = float(getattr(policy, "log_param_min", -5.0))
     desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
     desc.num_components = int(getattr(policy, "num_components", 0) or 0)

@@ -273,6 +273,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (!e || !d || !blob) return AZG_E_INVALID;
     if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
     if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
+    if (d->activation < 0 || d->activation > AZG_ACT_HARDSWISH) return fail(e, AZG_E_INVALID, "unknown activation");
     if (d->in_dim != e->S_obs) return fail(e, AZG_E_INVALID, "in_dim does not match the env observation");
     int ncomp = 0;
     if (e->cfg.mode == AZG_MODE_CONTINUOUS) {

@@ -46,7 +46,11 @@ __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
         f32x4 neg = __builtin_elementwise_min(v, zero);
         return pos + expm1f4_nonpos(neg);
     }
-    return pos;
+    if (act == AZG_ACT_RELU) return pos;
+    // the remaining activations (leakyrelu, relu6, silu, hardswish) are not on any benchmarked path: scalar, shared with the host
+    f32x4 r;
+    r.x = azg_activation(act, v.x); r.y = azg_activation(act, v.y); r.z = azg_activation(act, v.z); r.w = azg_activation(act, v.w);
+    return r;
 }
 
 __device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {

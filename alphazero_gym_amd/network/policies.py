@@ -14,7 +14,8 @@ import torch.nn.functional as F
 
 from .distributions import SquashedNormal
 
-_ACTIVATIONS = {"relu": nn.ReLU, "elu": nn.ELU}
+_ACTIVATIONS = {"relu": nn.ReLU, "elu": nn.ELU, "leakyrelu": nn.LeakyReLU, "relu6": nn.ReLU6, "silu": nn.SiLU, "swish": nn.SiLU,
+                "hardswish": nn.Hardswish}   # alphazero/network/utils.py:5-14
 
 
 def _trunk(in_dim: int, hidden: List[int], nonlinearity: str, layernorm: bool) -> nn.Sequential:
@@ -22,7 +23,7 @@ def _trunk(in_dim: int, hidden: List[int], nonlinearity: str, layernorm: bool) -
         raise NotImplementedError("layernorm=True is not supported by the MI355X engine yet")
     key = nonlinearity.lower().replace(" ", "")
     if key not in _ACTIVATIONS:
-        raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the engine implements relu and elu")
+        raise NotImplementedError(f"nonlinearity {nonlinearity!r}: one of {sorted(_ACTIVATIONS)}")
     layers, k = [], in_dim
     for h in hidden:
         layers += [nn.Linear(k, h), _ACTIVATIONS[key]()]

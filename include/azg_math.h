@@ -95,6 +95,21 @@ AZG_HD float azg_tanhf(float z) {
     return z < 0.0f ? -t : t;
 }
 
+/* trunk activations with torch's default parameters (alphazero/network/utils.py:5-14): 0 relu, 1 elu (alpha 1), 2 leakyrelu
+ * (slope 0.01), 3 relu6, 4 silu/swish x*sigmoid(x), 5 hardswish x*relu6(x+3)/6 */
+AZG_HD float azg_activation(int act, float x) {
+    float pos = x > 0.0f ? x : 0.0f;
+    float neg = x > 0.0f ? 0.0f : x;
+    switch (act) {
+        case 1: return pos + azg_expm1f(neg);
+        case 2: return pos + 0.01f * neg;
+        case 3: return pos < 6.0f ? pos : 6.0f;
+        case 4: return x / (1.0f + azg_expf(-x));
+        case 5: { float t = x + 3.0f; t = t > 0.0f ? t : 0.0f; t = t < 6.0f ? t : 6.0f; return (x * t) / 6.0f; }
+        default: return pos;
+    }
+}
+
 /* ln(x) for x in (0, +inf) normal floats */
 AZG_HD float azg_logf(float x) {
     uint32_t ix = azg_f2u(x);

@@ -35,8 +35,8 @@ enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2 };
 enum { AZG_MODE_DISCRETE = 0, AZG_MODE_CONTINUOUS = 1 };
 /* V_target_policy (mcts.py:299-304) */
 enum { AZG_VT_OFF_POLICY = 0, AZG_VT_ON_POLICY = 1, AZG_VT_GREEDY = 2 };
-/* trunk nonlinearity (alphazero/network/utils.py:5-14; configs use relu and elu) */
-enum { AZG_ACT_RELU = 0, AZG_ACT_ELU = 1 };
+/* trunk nonlinearity (alphazero/network/utils.py:5-14; the configs use relu and elu; swish == silu) */
+enum { AZG_ACT_RELU = 0, AZG_ACT_ELU = 1, AZG_ACT_LEAKYRELU = 2, AZG_ACT_RELU6 = 3, AZG_ACT_SILU = 4, AZG_ACT_HARDSWISH = 5 };
 
 #define AZG_MAX_HIDDEN_LAYERS 8
 

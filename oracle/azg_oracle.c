@@ -177,10 +177,7 @@ static inline int perm_k(int i) {
     return 16 * t + 4 * g + r;
 }
 
-static float act_fn(int act, float x) {
-    if (act == AZG_ACT_ELU) return x > 0.0f ? x : azg_expm1f(x);
-    return x > 0.0f ? x : 0.0f;
-}
+static float act_fn(int act, float x) { return azg_activation(act, x); }
 
 /* out[0] = V, out[1..] = raw distribution head */
 static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
@@ -327,6 +324,7 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (!e || !d || !blob) return AZG_E_INVALID;
     if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
     if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
+    if (d->activation < 0 || d->activation > AZG_ACT_HARDSWISH) return fail(e, AZG_E_INVALID, "unknown activation");
     if (d->in_dim != e->S_obs) return fail(e, AZG_E_INVALID, "in_dim does not match the env observation");
     if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
         int C = d->num_components >= 2 ? d->num_components : 0;

@@ -318,6 +318,22 @@ def run_t2():
         out[f"{name}_V"] = pol.predict_V(x).reshape(-1)
         out[f"{name}_mu"] = mu.numpy().reshape(-1)
         out[f"{name}_sigma"] = sigma.numpy().reshape(-1)
+    # the other trunk nonlinearities of alphazero/network/utils.py:5-14
+    for act in ("leakyrelu", "relu6", "swish", "hardswish"):
+        hidden = [64, 64]
+        blob = O.make_weights(36, 3, hidden, 2, scale=3.0)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity=act,
+                          num_components=1, action_bound=2.0)
+        set_policy_weights(pol, blob, 3, hidden, 2)
+        th = rng.uniform(-np.pi, np.pi, 64); thd = rng.uniform(-8, 8, 64)
+        obs = np.stack([np.cos(th), np.sin(th), thd], 1).astype(np.float32)
+        with torch.no_grad():
+            pol.eval()
+            mu, sigma, V = pol(torch.from_numpy(obs))
+        out[f"a_{act}_obs"] = obs
+        out[f"a_{act}_V"] = V.numpy().reshape(-1)
+        out[f"a_{act}_mu"] = mu.numpy().reshape(-1)
+        out[f"a_{act}_sigma"] = sigma.numpy().reshape(-1)
     # the reference's default continuous head: 2-component Gaussian mixture (config/policy/ContinuousPolicy.yaml:7)
     for name, hidden, nc in (("g128x3", [128, 128, 128], 2), ("g64c3", [64, 64], 3)):
         blob = O.make_weights(35, 3, hidden, 3 * nc)

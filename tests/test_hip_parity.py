@@ -94,6 +94,11 @@ CONFIGS = [
     (0, 0, [128, 128], "relu", 100, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
     (0, 0, [64, 64], "elu", 60, dict(c_uct=20.0, gamma=0.95, epsilon=0.1, num_actions=2, v_target="on_policy")),
     (0, 0, [256, 256], "relu", 80, dict(c_uct=5.0, gamma=0.99, num_actions=2)),
+    # the other trunk nonlinearities
+    (2, 1, [64, 64], "leakyrelu", 30, dict(c_uct=0.05, gamma=1.0)),
+    (2, 1, [128, 128], "silu", 30, dict(c_uct=0.05, gamma=1.0)),
+    (0, 0, [64, 64], "hardswish", 40, dict(c_uct=4.0, gamma=1.0, num_actions=2)),
+    (0, 0, [64], "relu6", 40, dict(c_uct=4.0, gamma=1.0, num_actions=2)),
     # Gaussian-mixture policy heads (the reference's default continuous config: 2 components, 3x128 ELU)
     (2, 1, [128, 128, 128], "elu", 60, dict(c_uct=0.05, gamma=1.0, _ncomp=2)),
     (1, 1, [64, 64], "elu", 40, dict(c_uct=0.2, gamma=0.95, c_pw=1.5, kappa=0.6, _ncomp=3)),

@@ -29,6 +29,13 @@ def test_mlp_matches_torch_policies():
         np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 0], z[f"{name}_mu"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 1], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
+    for act in ("leakyrelu", "relu6", "swish", "hardswish"):
+        e = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
+        e.set_weights(_capi.make_desc(3, [64, 64], 2, act), O.make_weights(36, 3, [64, 64], 2, scale=3.0))
+        v, d, _ = e.mlp_eval(z[f"a_{act}_obs"])
+        np.testing.assert_allclose(v, z[f"a_{act}_V"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 0], z[f"a_{act}_mu"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 1], z[f"a_{act}_sigma"], atol=TOL, rtol=TOL)
     # Gaussian-mixture head (DiagonalGMMPolicy, the reference's default continuous policy)
     for name, hidden, nc in (("g128x3", [128, 128, 128], 2), ("g64c3", [64, 64], 3)):
         e = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
