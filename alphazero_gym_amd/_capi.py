@@ -62,7 +62,7 @@ class AzgMlpDesc(C.Structure):
         ("log_std_min", C.c_float),
         ("log_std_max", C.c_float),
         ("num_components", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("layernorm", C.c_int32),
     ]
 
 
@@ -125,17 +125,21 @@ def policy_blob(policy):
     and for the reference's DiscretePolicy / DiagonalNormalPolicy objects alike (same attribute names:
     trunk, value_head, dist_head, hidden_dimensions, state_dim; alphazero/network/policies.py:101-120, 238-259)."""
     hidden = list(policy.hidden_dimensions)
-    linears, acts = [], set()
+    linears, norms, acts = [], [], set()
     for mod in policy.trunk:
         name = type(mod).__name__
         if name == "Linear":
             linears.append(mod)
+        elif name == "LayerNorm":
+            norms.append(mod)
         elif name in _ACT_MODULES:
             acts.add(_ACT_MODULES[name])
         else:
-            raise NotImplementedError(f"trunk module {name}: the engine implements Linear + pointwise-activation trunks (no LayerNorm)")
-    if len(acts) != 1 or len(linears) != len(hidden):
+            raise NotImplementedError(f"trunk module {name}: the engine implements Linear + activation (+ LayerNorm) trunks")
+    if len(acts) != 1 or len(linears) != len(hidden) or len(norms) not in (0, len(hidden)):
         raise NotImplementedError("unsupported trunk structure")
+    if any(abs(n.eps - 1e-5) > 1e-12 or not n.elementwise_affine for n in norms):
+        raise NotImplementedError("LayerNorm must use eps=1e-5 and elementwise_affine=True (the torch defaults)")
     desc = AzgMlpDesc()
     desc.struct_size = C.sizeof(AzgMlpDesc)
     desc.in_dim = policy.state_dim
@@ -147,14 +151,19 @@ def policy_blob(policy):
     desc.log_std_min = float(getattr(policy, "log_param_min", -5.0))
     desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
     desc.num_components = int(getattr(policy, "num_components", 0) or 0)
+    desc.layernorm = 1 if norms else 0
     parts = []
-    for mod in linears + [policy.value_head, policy.dist_head]:
+    for i, mod in enumerate(linears):
+        parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
+        if norms:
+            parts += [norms[i].weight.detach().cpu().numpy().ravel(), norms[i].bias.detach().cpu().numpy().ravel()]
+    for mod in (policy.value_head, policy.dist_head):
         parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
     blob = np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
     return desc, blob
 
 
-def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=2.0, num_components=0):
+def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=2.0, num_components=0, layernorm=False):
     desc = AzgMlpDesc()
     desc.struct_size = C.sizeof(AzgMlpDesc)
     desc.in_dim = in_dim
@@ -166,6 +175,7 @@ def make_desc(in_dim, hidden, n_dist, activation, log_std_min=-5.0, log_std_max=
     desc.log_std_min = log_std_min
     desc.log_std_max = log_std_max
     desc.num_components = num_components
+    desc.layernorm = int(bool(layernorm))
     return desc
 
 

@@ -286,7 +286,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     int k = d->in_dim, hmax = 0;
     for (int l = 0; l < d->n_hidden; ++l) {
         if (d->hidden[l] < 1 || d->hidden[l] > 4096) return fail(e, AZG_E_INVALID, "hidden width out of range");
-        need += (size_t)d->hidden[l] * k + d->hidden[l];
+        need += (size_t)d->hidden[l] * k + d->hidden[l] + (d->layernorm ? 2 * (size_t)d->hidden[l] : 0);
         k = d->hidden[l];
         if (k > hmax) hmax = k;
     }
@@ -301,7 +301,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     e->weight_allocs.clear();
     const int NT = HP / 16, S4 = HP / 16;
     // unpack the torch-layout blob into zero-padded [HP][Kp] matrices
-    std::vector<std::vector<float>> Wd(d->n_hidden), bd(d->n_hidden);
+    std::vector<std::vector<float>> Wd(d->n_hidden), bd(d->n_hidden), gd(d->n_hidden), ed(d->n_hidden);
     const float* p = blob;
     int kt = d->in_dim, kp = 4;
     for (int l = 0; l < d->n_hidden; ++l) {
@@ -313,6 +313,14 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         p += (size_t)h * kt;
         for (int n = 0; n < h; ++n) bd[l][n] = p[n];
         p += h;
+        gd[l].assign(HP, 0.0f);
+        ed[l].assign(HP, 0.0f);
+        if (d->layernorm) {
+            for (int n = 0; n < h; ++n) gd[l][n] = p[n];
+            p += h;
+            for (int n = 0; n < h; ++n) ed[l][n] = p[n];
+            p += h;
+        }
         kt = h; kp = HP;
     }
     const int n_out = 1 + d->n_dist;
@@ -382,12 +390,34 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         if (dalloc(e, &rd, (size_t)e->cfg.n_trees * d->n_dist, e->weight_allocs)) return AZG_E_DEVICE;
         e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
     }
+    e->P.layernorm = d->layernorm ? 1 : 0;
+    for (int l = 0; l < d->n_hidden; ++l) {
+        e->P.Htrue[l] = d->hidden[l];
+        e->P.lng[l] = nullptr; e->P.lnb[l] = nullptr;
+        if (!d->layernorm) continue;
+        std::vector<float> gs((size_t)NT * 64 * 4), es((size_t)NT * 64 * 4);
+        for (int t = 0; t < NT; ++t)
+            for (int l64 = 0; l64 < 64; ++l64)
+                for (int r = 0; r < 4; ++r) {
+                    gs[((size_t)t * 64 + l64) * 4 + r] = gd[l][16 * t + 4 * (l64 >> 4) + r];
+                    es[((size_t)t * 64 + l64) * 4 + r] = ed[l][16 * t + 4 * (l64 >> 4) + r];
+                }
+        float *dg, *de;
+        if (dalloc(e, &dg, gs.size(), e->weight_allocs)) return AZG_E_DEVICE;
+        if (dalloc(e, &de, es.size(), e->weight_allocs)) return AZG_E_DEVICE;
+        HIPCHK(e, hipMemcpy(dg, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(de, es.data(), es.size() * 4, hipMemcpyHostToDevice));
+        e->P.lng[l] = (const f32x4*)dg;
+        e->P.lnb[l] = (const f32x4*)de;
+    }
     e->HP = HP; e->n_hidden = d->n_hidden; e->n_out = n_out; e->act = d->activation;
     e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
     // hidden->hidden layers that fit the register file stay there for the whole search
     int nhh = d->n_hidden - 1;
     int regs = nhh * (HP * HP / 256);   // VGPRs per lane: each of the 4 waves holds a quarter of every layer
     e->nreg = (nhh >= 1 && nhh <= 3 && regs <= 288) ? nhh : 0;
+    // LayerNorm and the rare activations live in the weight-streaming kernels only (keeps the register-resident kernels lean)
+    if (d->layernorm || (d->activation != AZG_ACT_RELU && d->activation != AZG_ACT_ELU)) e->nreg = 0;
     const char* force = getenv("AZG_FORCE_STREAM_WEIGHTS");
     if (force && force[0] == '1') e->nreg = 0;
     e->mlp_ready = 1;

@@ -39,6 +39,7 @@ __device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 x) {
 
 // ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(+-0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit
 // for bit (the sign of a zero that v_max/v_min may pick differently from the host's select vanishes in the sum)
+template <bool RARE = true>
 __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 pos = __builtin_elementwise_max(v, zero);
@@ -46,8 +47,9 @@ __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
         f32x4 neg = __builtin_elementwise_min(v, zero);
         return pos + expm1f4_nonpos(neg);
     }
-    if (act == AZG_ACT_RELU) return pos;
-    // the remaining activations (leakyrelu, relu6, silu, hardswish) are not on any benchmarked path: scalar, shared with the host
+    if (!RARE || act == AZG_ACT_RELU) return pos;
+    // the remaining activations (leakyrelu, relu6, silu, hardswish) are compiled into the weight-streaming kernels only
+    // (the host selects those kernels for them): scalar, shared with the host
     f32x4 r;
     r.x = azg_activation(act, v.x); r.y = azg_activation(act, v.y); r.z = azg_activation(act, v.z); r.w = azg_activation(act, v.w);
     return r;
@@ -66,12 +68,57 @@ template <int HP, int NREG>
 struct WRegs {
     static constexpr int NTW = HP / 64;
     static constexpr int S4 = HP / 16;
+    static constexpr int NW0 = HP <= 256 ? NTW : 1;   // first-layer weights are register-resident up to HP = 256
     f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
     f32x4 b[NREG > 0 ? NREG : 1][NTW];
     f32x4 wh[NTW];   // head weights of this wave's K-chunk
-    float w0[NTW];   // first layer (K <= 4: one k-step per tile)
-    f32x4 b0[NTW];
+    float w0[NW0];   // first layer (K <= 4: one k-step per tile)
+    f32x4 b0[NW0];
 };
+
+// nn.LayerNorm (eps 1e-5, affine) over the true units of one trunk layer for the workgroup's 16 trees.  A thread holds 16 units
+// of one tree (its wave's tiles, D-register layout); it sums its own values, the 4 lane groups of the wave are added in order,
+// then the 4 waves through LDS (s_ln: two 64-float buffers, one per reduction, so one barrier per reduction suffices).
+__device__ __forceinline__ float ln_reduce(float s, float* buf, int wave, int lane) {
+    const int tree = lane & 15;
+    float v0 = __shfl(s, tree), v1 = __shfl(s, 16 + tree), v2 = __shfl(s, 32 + tree), v3 = __shfl(s, 48 + tree);
+    float wsum = ((v0 + v1) + v2) + v3;
+    if (lane < 16) buf[wave * 16 + tree] = wsum;
+    __syncthreads();
+    return ((buf[tree] + buf[16 + tree]) + buf[32 + tree]) + buf[48 + tree];
+}
+
+template <int HP>
+__device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4* h, float* s_ln, int wave, int lane) {
+    constexpr int NTW = HP / 64;
+    const int H = P.Htrue[layer];
+    const int g = lane >> 4;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { s = s + h[i].x; s = s + h[i].y; s = s + h[i].z; s = s + h[i].w; }
+    const float mean = ln_reduce(s, s_ln, wave, lane) / (float)H;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int u0 = 16 * (wave * NTW + i) + 4 * g;
+        float d;
+        d = u0 + 0 < H ? h[i].x - mean : 0.0f; s2 = s2 + d * d;
+        d = u0 + 1 < H ? h[i].y - mean : 0.0f; s2 = s2 + d * d;
+        d = u0 + 2 < H ? h[i].z - mean : 0.0f; s2 = s2 + d * d;
+        d = u0 + 3 < H ? h[i].w - mean : 0.0f; s2 = s2 + d * d;
+    }
+    const float var = ln_reduce(s2, s_ln + 64, wave, lane) / (float)H;
+    const float inv = 1.0f / __builtin_sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int u0 = 16 * (wave * NTW + i) + 4 * g;
+        const f32x4 ga = P.lng[layer][(wave * NTW + i) * 64 + lane], be = P.lnb[layer][(wave * NTW + i) * 64 + lane];
+        h[i].x = u0 + 0 < H ? ((h[i].x - mean) * inv) * ga.x + be.x : 0.0f;
+        h[i].y = u0 + 1 < H ? ((h[i].y - mean) * inv) * ga.y + be.y : 0.0f;
+        h[i].z = u0 + 2 < H ? ((h[i].z - mean) * inv) * ga.z + be.z : 0.0f;
+        h[i].w = u0 + 3 < H ? ((h[i].w - mean) * inv) * ga.w + be.w : 0.0f;
+    }
+}
 
 // The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  Result: parts[4 waves][64 lanes] = every
 // wave's partial head sums (head_output() combines them).  Activations cross waves through the two act buffers
@@ -79,7 +126,7 @@ struct WRegs {
 // registers until the next layer publishes it, and the last layer's output feeds the head MFMAs directly.
 template <int HP, int NREG>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
-                                            f32x4* parts, int wave, int lane
+                                            f32x4* parts, float* s_ln, int wave, int lane
 #ifdef AZG_STAMPS
                                             , unsigned long long* st_acc
 #endif
@@ -92,7 +139,16 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
     {
         float b = obsT[lane];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
+        for (int i = 0; i < NTW; ++i) {
+            if constexpr (HP <= 256) {
+                h[i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
+            } else {   // wide layers: first-layer weights are not kept in registers
+                const int nt = wave * NTW + i;
+                h[i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0));
+            }
+        }
+        // LayerNorm is compiled into the weight-streaming kernels only (the host selects them when layernorm is on)
+        if constexpr (NREG == 0) { if (P.layernorm) layer_norm_wg<HP>(P, 0, h, s_ln, wave, lane); }
     }
     f32x4* buf = actA;
     f32x4* other = actB;
@@ -126,7 +182,7 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             }
             STAMP(m2);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
+            for (int i = 0; i < NTW; ++i) h[i] = act4<NREG == 0>(P.act, acc[i]);
             STAMP(m2b);
             if (l == 0) { STAMP_ADD(4, m0, m1); }
             STAMP_ADD(5, m1, m2);
@@ -141,26 +197,32 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             __syncthreads();
             const f32x4* W = P.Wl[l - 1];
             const f32x4* bb = P.bl[l - 1];
-            f32x4 acc[NTW];
+            // tiles in groups of at most 4 (wide layers: 16 tiles per wave would not fit the register file)
+            constexpr int TG = NTW < 4 ? NTW : 4;
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i] = bb[(wave * NTW + i) * 64 + lane];
+            for (int tg = 0; tg < NTW; tg += TG) {
+                f32x4 acc[TG];
+#pragma unroll
+                for (int i = 0; i < TG; ++i) acc[i] = bb[(wave * NTW + tg + i) * 64 + lane];
 #pragma unroll 2
-            for (int s4 = 0; s4 < S4; ++s4) {
-                f32x4 b = buf[s4 * 64 + lane];
-                f32x4 a[NTW];
+                for (int s4 = 0; s4 < S4; ++s4) {
+                    f32x4 b = buf[s4 * 64 + lane];
+                    f32x4 a[TG];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) a[i] = W[((wave * NTW + i) * S4 + s4) * 64 + lane];
+                    for (int i = 0; i < TG; ++i) a[i] = W[((wave * NTW + tg + i) * S4 + s4) * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+                    for (int i = 0; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+                    for (int i = 0; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+                    for (int i = 0; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+                    for (int i = 0; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TG; ++i) h[tg + i] = act4<NREG == 0>(P.act, acc[i]);
             }
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) h[i] = act4(P.act, acc[i]);
+            if (P.layernorm) layer_norm_wg<HP>(P, l, h, s_ln, wave, lane);
             f32x4* t = buf; buf = other; other = t;
         }
     }

@@ -1,6 +1,6 @@
 // records.h -- tree record layouts, kernel parameter block, diagnostic stamp macros (device + host).
-#include <hip/hip_runtime.h>
 #pragma once
+#include <hip/hip_runtime.h>
 #include "../../include/azg_math.h"
 #include "../../include/azgym.h"
 
@@ -75,6 +75,10 @@ struct KParams {
     const f32x4* bl[MAX_STREAM_LAYERS]; // [HP/16][64]
     const f32x4* Whead;      // [HP/16 s4][64]
     const float* bhead;      // [16]
+    int layernorm;           // nn.LayerNorm after every trunk activation
+    int Htrue[MAX_STREAM_LAYERS];          // true (unpadded) width of trunk layer l
+    const f32x4* lng[MAX_STREAM_LAYERS];   // LayerNorm weight of trunk layer l, [HP/16][64] (D-register layout, zero padded)
+    const f32x4* lnb[MAX_STREAM_LAYERS];   // LayerNorm bias
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };
 

@@ -14,6 +14,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     __shared__ f32x4 s_parts[4 * 64];
     __shared__ float s_obsT[4 * 16];
     __shared__ float s_bhead[16];
+    __shared__ float s_ln[2 * 64];
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, two activation buffers, (TLDS) the 16 trees' hot records
 
     const int tid = threadIdx.x;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
 
     // register-resident weights
     WRegs<HP, NREG> wr;
-    {
+    if constexpr (HP <= 256) {
         constexpr int NTW0 = HP / 64;
 #pragma unroll
         for (int i = 0; i < NTW0; ++i) {
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
         int any = __syncthreads_or(need_eval ? 1 : 0);
         STAMP(t_b);
 #ifdef AZG_STAMPS
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, wave, lane, st_acc);
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, wave, lane);
+        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
 

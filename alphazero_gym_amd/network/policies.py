@@ -19,14 +19,14 @@ _ACTIVATIONS = {"relu": nn.ReLU, "elu": nn.ELU, "leakyrelu": nn.LeakyReLU, "relu
 
 
 def _trunk(in_dim: int, hidden: List[int], nonlinearity: str, layernorm: bool) -> nn.Sequential:
-    if layernorm:
-        raise NotImplementedError("layernorm=True is not supported by the MI355X engine yet")
     key = nonlinearity.lower().replace(" ", "")
     if key not in _ACTIVATIONS:
         raise NotImplementedError(f"nonlinearity {nonlinearity!r}: one of {sorted(_ACTIVATIONS)}")
     layers, k = [], in_dim
     for h in hidden:
         layers += [nn.Linear(k, h), _ACTIVATIONS[key]()]
+        if layernorm:
+            layers.append(nn.LayerNorm(normalized_shape=h))   # after the activation, like the reference (policies.py:105-106)
         k = h
     return nn.Sequential(*layers)
 

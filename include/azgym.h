@@ -78,7 +78,8 @@ typedef struct azg_mlp_desc {
     float log_std_max;
     int32_t num_components; /* continuous only: 0/1 = squashed Normal (n_dist = 2); C >= 2 = Gaussian mixture,
                              * DiagonalGMMPolicy (policies.py:502-669), n_dist = 3C laid out [mu_0..mu_C-1, log_std_0.., log_coeff_0..] */
-    int32_t reserved1;
+    int32_t layernorm;      /* 1: nn.LayerNorm (eps 1e-5, affine) after every trunk activation (policies.py:105-118, 242-255);
+                             * the blob then holds, per trunk layer, W, b, ln_weight[out], ln_bias[out] */
 } azg_mlp_desc;
 
 typedef struct azg_engine azg_engine;

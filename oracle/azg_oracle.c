@@ -47,6 +47,9 @@ typedef struct {
     int act;
     float ls_min, ls_max;
     int ncomp;                 /* mixture components (0: squashed Normal) */
+    int layernorm;
+    float* lng[AZG_MAX_HIDDEN_LAYERS];   /* LayerNorm weight / bias, zero padded to hidp */
+    float* lnb[AZG_MAX_HIDDEN_LAYERS];
     float* W[AZG_MAX_HIDDEN_LAYERS];  /* [hidp][kp] zero padded; kp = in_dim (layer 0) or hidp[l-1] */
     float* b[AZG_MAX_HIDDEN_LAYERS];
     float* Wh;                 /* [n_out][hidp_last] */
@@ -179,6 +182,34 @@ static inline int perm_k(int i) {
 
 static float act_fn(int act, float x) { return azg_activation(act, x); }
 
+/* nn.LayerNorm (eps 1e-5) over the H true units of a layer, in the engine's summation order: the 256 threads of a workgroup
+ * each hold 16 units of one tree (wave w, lane group g: units 16(w*NTW+i)+4g+r); a thread sums its own, then the 4 lane groups
+ * of a wave are added in order, then the 4 waves.  y = ((h - mean) * (1/sqrt(var + eps))) * weight + bias, unfused. */
+static float ln_sum(const float* v, int hp) {
+    int ntw = hp / 64;
+    float total = 0.0f;
+    for (int w = 0; w < 4; ++w) {
+        float wave = 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            float s = 0.0f;
+            for (int i = 0; i < ntw; ++i)
+                for (int r = 0; r < 4; ++r) s = s + v[16 * (w * ntw + i) + 4 * g + r];
+            wave = wave + s;
+        }
+        total = total + wave;
+    }
+    return total;
+}
+
+static void layer_norm(float* h, int hp, int H, const float* gamma, const float* beta) {
+    float tmp[4096];
+    float mean = ln_sum(h, hp) / (float)H;
+    for (int n = 0; n < hp; ++n) { float d = n < H ? h[n] - mean : 0.0f; tmp[n] = d * d; }
+    float var = ln_sum(tmp, hp) / (float)H;
+    float inv = 1.0f / __builtin_sqrtf(var + 1e-5f);
+    for (int n = 0; n < hp; ++n) h[n] = n < H ? ((h[n] - mean) * inv) * gamma[n] + beta[n] : 0.0f;
+}
+
 /* out[0] = V, out[1..] = raw distribution head */
 static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
     float bufa[4096], bufb[4096];
@@ -198,6 +229,7 @@ static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
             }
             h[n] = act_fn(m->act, acc);
         }
+        if (m->layernorm) layer_norm(h, hp, m->hid[l], m->lng[l], m->lnb[l]);
         float* t = x; x = h; h = t;
         kp = hp;
     }
@@ -262,7 +294,7 @@ static void free_tree(tree_t* t) {
 void azo_engine_destroy(azg_engine* e) {
     if (!e) return;
     if (e->trees) { for (int i = 0; i < e->cfg.n_trees; ++i) free_tree(&e->trees[i]); free(e->trees); }
-    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.b[l]); }
+    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.b[l]); free(e->mlp.lng[l]); free(e->mlp.lnb[l]); }
     free(e->mlp.Wh); free(e->mlp.bh); free(e->pw_need); free(e->roots); free(e->carry);
     free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
     free(e);
@@ -341,12 +373,13 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     int k = d->in_dim;
     for (int l = 0; l < d->n_hidden; ++l) {
         if (d->hidden[l] < 1 || d->hidden[l] > 4096) return fail(e, AZG_E_INVALID, "hidden width out of range");
-        need += (size_t)d->hidden[l] * k + d->hidden[l];
+        need += (size_t)d->hidden[l] * k + d->hidden[l] + (d->layernorm ? 2 * (size_t)d->hidden[l] : 0);
         k = d->hidden[l];
     }
     need += (size_t)(1 + d->n_dist) * k + (1 + d->n_dist);
     if (need != n_floats) return fail(e, AZG_E_INVALID, "weight blob size mismatch");
     mlp_t* m = &e->mlp;
+    m->layernorm = d->layernorm ? 1 : 0;
     for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(m->W[l]); free(m->b[l]); m->W[l] = NULL; m->b[l] = NULL; }
     free(m->Wh); free(m->bh);
     m->n_layers = d->n_hidden; m->in_dim = d->in_dim; m->n_out = 1 + d->n_dist; m->act = d->activation;
@@ -367,6 +400,12 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         p += (size_t)h * kt;
         memcpy(m->b[l], p, sizeof(float) * h);
         p += h;
+        free(m->lng[l]); free(m->lnb[l]);
+        m->lng[l] = (float*)calloc(hp, 4); m->lnb[l] = (float*)calloc(hp, 4);
+        if (d->layernorm) {
+            memcpy(m->lng[l], p, sizeof(float) * h); p += h;
+            memcpy(m->lnb[l], p, sizeof(float) * h); p += h;
+        }
         kt = h; kp = hp;
     }
     m->Wh = (float*)calloc((size_t)m->n_out * kp, 4);

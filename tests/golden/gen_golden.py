@@ -299,6 +299,19 @@ def set_policy_weights(pol, blob, in_dim, hidden, n_dist):
     assert p == blob.size
 
 
+def set_layernorm_params(pol, seed):
+    """Non-trivial LayerNorm weight/bias (torch initialises them to 1/0); returns them flattened per layer."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for m in pol.trunk:
+        if isinstance(m, torch.nn.LayerNorm):
+            w = rng.uniform(0.5, 1.5, m.weight.shape).astype(np.float32)
+            b = rng.uniform(-0.3, 0.3, m.bias.shape).astype(np.float32)
+            m.weight.data = torch.from_numpy(w.copy()); m.bias.data = torch.from_numpy(b.copy())
+            out.append((w, b))
+    return out
+
+
 def run_t2():
     out = {}
     rng = np.random.Generator(np.random.PCG64(2024))
@@ -316,6 +329,22 @@ def run_t2():
             mu, sigma, V = pol(x)
         out[f"{name}_obs"] = obs
         out[f"{name}_V"] = pol.predict_V(x).reshape(-1)
+        out[f"{name}_mu"] = mu.numpy().reshape(-1)
+        out[f"{name}_sigma"] = sigma.numpy().reshape(-1)
+    # LayerNorm after every trunk activation (layernorm: true, policies.py:105-118); widths that are not multiples of 64
+    for name, hidden, act in (("ln_c64", [64, 64], "elu"), ("ln_c100", [100, 60], "relu")):
+        blob = O.make_weights(37, 3, hidden, 2, scale=2.0)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity=act,
+                          num_components=1, action_bound=2.0, layernorm=True)
+        set_policy_weights(pol, blob, 3, hidden, 2)
+        set_layernorm_params(pol, 38)
+        th = rng.uniform(-np.pi, np.pi, 64); thd = rng.uniform(-8, 8, 64)
+        obs = np.stack([np.cos(th), np.sin(th), thd], 1).astype(np.float32)
+        with torch.no_grad():
+            pol.eval()
+            mu, sigma, V = pol(torch.from_numpy(obs))
+        out[f"{name}_obs"] = obs
+        out[f"{name}_V"] = V.numpy().reshape(-1)
         out[f"{name}_mu"] = mu.numpy().reshape(-1)
         out[f"{name}_sigma"] = sigma.numpy().reshape(-1)
     # the other trunk nonlinearities of alphazero/network/utils.py:5-14

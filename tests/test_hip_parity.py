@@ -99,6 +99,10 @@ CONFIGS = [
     (2, 1, [128, 128], "silu", 30, dict(c_uct=0.05, gamma=1.0)),
     (0, 0, [64, 64], "hardswish", 40, dict(c_uct=4.0, gamma=1.0, num_actions=2)),
     (0, 0, [64], "relu6", 40, dict(c_uct=4.0, gamma=1.0, num_actions=2)),
+    # LayerNorm trunks (widths that are not multiples of 64 exercise the padded-unit mask)
+    (2, 1, [100, 60], "elu", 30, dict(c_uct=0.05, gamma=1.0, _ln=True)),
+    (2, 1, [256, 256], "relu", 30, dict(c_uct=0.05, gamma=1.0, _ln=True)),
+    (0, 0, [128, 128, 128], "silu", 30, dict(c_uct=4.0, gamma=1.0, num_actions=2, _ln=True)),
     # Gaussian-mixture policy heads (the reference's default continuous config: 2 components, 3x128 ELU)
     (2, 1, [128, 128, 128], "elu", 60, dict(c_uct=0.05, gamma=1.0, _ncomp=2)),
     (1, 1, [64, 64], "elu", 40, dict(c_uct=0.2, gamma=0.95, c_pw=1.5, kappa=0.6, _ncomp=3)),
@@ -121,6 +125,7 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
     ncomp = extra.pop("_ncomp", 0)
+    ln = extra.pop("_ln", False)
     if variant == "stream_weights":
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
     if variant == "global_tree":
@@ -128,8 +133,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
     in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else (4, 2)
-    desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp)
+    desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
     blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
+    if ln:
+        blob = O.add_layernorm(blob, in_dim, hidden, n_dist, 7)
     o = O.OracleEngine(**kw)
     roots = o.synthetic_roots()
     o.close()

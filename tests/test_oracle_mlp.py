@@ -29,6 +29,14 @@ def test_mlp_matches_torch_policies():
         np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 0], z[f"{name}_mu"], atol=TOL, rtol=TOL)
         np.testing.assert_allclose(d[:, 1], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
+    for name, hidden, act in (("ln_c64", [64, 64], "elu"), ("ln_c100", [100, 60], "relu")):
+        e = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
+        blob = O.add_layernorm(O.make_weights(37, 3, hidden, 2, scale=2.0), 3, hidden, 2, 38)
+        e.set_weights(_capi.make_desc(3, hidden, 2, act, layernorm=True), blob)
+        v, d, _ = e.mlp_eval(z[f"{name}_obs"])
+        np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 0], z[f"{name}_mu"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 1], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
     for act in ("leakyrelu", "relu6", "swish", "hardswish"):
         e = O.OracleEngine(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
         e.set_weights(_capi.make_desc(3, [64, 64], 2, act), O.make_weights(36, 3, [64, 64], 2, scale=3.0))
