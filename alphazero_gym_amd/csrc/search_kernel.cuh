@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                     }
                 }
                 // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
+                STAMP(t_w1);
+                STAMP_ADD(13, t_x, t_w1);  // widening (waits for the parent's cold record)
                 path_D += 1;
                 double ns[S], r, sn;
                 int done;
@@ -344,6 +346,8 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
                 }
                 float obs[4];
                 env_obs<ENV>(ns, obs, &sn);
+                STAMP(t_w2);
+                STAMP_ADD(14, t_w1, t_w2);  // env step + observation
                 if (sub == 0) {
                     Cold c;
 #pragma unroll
@@ -361,8 +365,10 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
             STAMP(t_y);
             STAMP_ADD(10, t_x, t_y);   // widen + env step + node creation
         }
+        STAMP(t_f);
         __threadfence_block();
         STAMP(t_e);
+        STAMP_ADD(15, t_f, t_e);   // store drain at the end of the tree phase
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase
         STAMP_ADD(1, t_b, t_c);   // network phase
         STAMP_ADD(2, t_c, t_d);   // finish leaf + backup

@@ -177,8 +177,7 @@ AZG_HD void azg_sincos(double x, double* sn, double* cs) {
     double hz = 0.5 * z;
     double w = 1.0 - hz;
     double c = w + (((1.0 - w) - hz) + (z * z) * pc);
-    long long n = (long long)nf;
-    int q = (int)(n & 3);
+    int q = ((int)nf) & 3;   /* |x| < 1e5: the quadrant count fits 32 bits */
     *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
     *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
@@ -187,7 +186,7 @@ AZG_HD void azg_sincos(double x, double* sn, double* cs) {
  * quotient estimate trunc(x * inv_y) may be off by one, which the sign of the first remainder reveals; the second fma
  * then computes x - q*y for the true floor quotient, which is exactly representable (the fmod property). */
 AZG_HD double azg_pymod(double x, double y, double inv_y) {
-    double qt = (double)(long long)(x * inv_y); /* trunc */
+    double qt = __builtin_trunc(x * inv_y);
     double r0 = AZG_FMA(-qt, y, x);
     double adj = r0 < 0.0 ? -1.0 : (r0 >= y ? 1.0 : 0.0);
     qt = qt + adj;

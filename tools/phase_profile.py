@@ -48,6 +48,9 @@ def main():
                                      "  A: finish leaf", "  B: descent", "  B: widen+env step+create"]):
         v = buf[:, i].astype(np.float64)
         print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
+    for i, nm in ((13, "  B: widen (cold wait+tanh)"), (14, "  B: env step + obs"), (15, "  B: store drain (fence)")):
+        v = buf[:, i].astype(np.float64)
+        print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
     b = buf.astype(np.float64)
     print(f"  B: UCT level   {b[:, 11].sum() / max(b[:, 12].sum(), 1):8.0f} cycles each, {b[:, 12].mean() / (n_sims + 1):.2f} per step (wave-level: max over 4 trees)")
 
