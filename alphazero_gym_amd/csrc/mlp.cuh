@@ -63,6 +63,11 @@ __device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {
     return acc;
 }
 
+// Head outputs are summed in chunks of the hidden vector (chains from 0), the chunk partials then added in order:
+// HP <= 256: 4 chunks of HP/4 positions (one per wave); wider layers: chunks of 64 positions (4 tiles), HP/64 of them.
+template <int HP>
+__host__ __device__ constexpr int head_chunks() { return HP <= 256 ? 4 : HP / 64; }
+
 // Register-resident hidden->hidden weights: wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer.
 template <int HP, int NREG>
 struct WRegs {
@@ -226,25 +231,32 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
             f32x4* t = buf; buf = other; other = t;
         }
     }
-    // heads: wave w sums its quarter of the hidden units (chain from 0) straight from its registers
+    // heads: every chunk of the wave's hidden units is a chain from 0, straight from registers
     {
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        constexpr int NSUB = HP <= 256 ? 1 : NTW / 4;   // chunks per wave
+        constexpr int TPC = NTW / NSUB;                  // tiles per chunk
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            f32x4 a = (NREG > 0) ? wr.wh[i] : P.Whead[(wave * NTW + i) * 64 + lane];
-            acc = mfma4(a, h[i], acc);
+        for (int sc = 0; sc < NSUB; ++sc) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < TPC; ++i) {
+                const int ti = sc * TPC + i;
+                f32x4 a = (NREG > 0) ? wr.wh[ti] : P.Whead[(wave * NTW + ti) * 64 + lane];
+                acc = mfma4(a, h[ti], acc);
+            }
+            parts[(wave * NSUB + sc) * 64 + lane] = acc;
         }
-        parts[wave * 64 + lane] = acc;
     }
     __syncthreads();
 }
 
-// network output o of tree tl: bias + the four waves' partial sums, added in wave order (the oracle's summation order)
+// network output o of tree tl: bias + the NCH chunk partials, added in chunk order (the oracle's summation order)
+template <int NCH>
 __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_bhead, int tl, int o) {
     float total = s_bhead[o];
     const int idx = (o >> 2) * 16 + tl;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NCH; ++w) {
         f32x4 pv = parts[w * 64 + idx];
         float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
         total = total + p;
@@ -256,24 +268,25 @@ __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_
 // DiagonalGMMPolicy head (policies.py:544-560) of one node from the raw network outputs: mu_c, sigma_c = exp(clamp(log_std_c)),
 // cumulative softmax(log_coeff) in component order.  d[15] = mu[5] | sigma[5] | cum[5] (fixed stride so that every index
 // below is a compile-time constant and the arrays stay in registers).
+template <int NCH>
 __device__ __forceinline__ void gmm_params(const f32x4* parts, const float* s_bhead, int tl, int C, float ls_min, float ls_max, float* d) {
-    float mx = head_output(parts, s_bhead, tl, 1 + 2 * C);
+    float mx = head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C);
 #pragma unroll
     for (int c = 1; c < GMM_MAXC; ++c)
-        if (c < C) { float v = head_output(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
+        if (c < C) { float v = head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
     float ex[GMM_MAXC], sum = 0.0f, cum = 0.0f;
 #pragma unroll
     for (int c = 0; c < GMM_MAXC; ++c) {
         ex[c] = 0.0f;
-        if (c < C) { ex[c] = azg_expf(head_output(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
+        if (c < C) { ex[c] = azg_expf(head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
     }
 #pragma unroll
     for (int c = 0; c < GMM_MAXC; ++c) {
         d[c] = 0.0f; d[GMM_MAXC + c] = 0.0f; d[2 * GMM_MAXC + c] = 2.0f;
         if (c < C) {
-            float ls = head_output(parts, s_bhead, tl, 1 + C + c);
+            float ls = head_output<NCH>(parts, s_bhead, tl, 1 + C + c);
             ls = ls < ls_min ? ls_min : (ls > ls_max ? ls_max : ls);
-            d[c] = head_output(parts, s_bhead, tl, 1 + c);
+            d[c] = head_output<NCH>(parts, s_bhead, tl, 1 + c);
             d[GMM_MAXC + c] = azg_expf(ls);
             cum = cum + ex[c] / sum;
             d[2 * GMM_MAXC + c] = cum;

@@ -1,0 +1,283 @@
+// tree_phases.cuh -- the two tree phases of one simulation step for one tree (16 lanes), shared by the persistent search
+// kernel (search_kernel.cuh) and the lock-step kernels for wide networks (lockstep.cuh).
+#pragma once
+#include "records.h"
+#include "env.cuh"
+#include "mlp.cuh"
+#include "tree.cuh"
+
+// What a 16-lane group carries from one phase to the next (group-uniform unless noted)
+struct TreeState {
+    int nrec;             // records allocated so far
+    unsigned eps_draws;   // epsilon-greedy draws consumed
+    int leaf;             // record to be evaluated / backed up
+    bool need_eval;       // the leaf needs a network evaluation
+    int path_D;           // depth of the leaf on the current trace
+    int my_depth, pid;    // per lane: slot (depth & 15) of the trace's path: depth and record id ...
+    double pr, pW;        // ... and that record's reward and cumulative return W (consumed by backup_path)
+    int kbase;            // progressive-widening noise cache: lane `sub` holds the N(0,1) draw of record kbase + sub
+    float eps_c;          // per lane
+};
+
+// initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][16] input block of the tree's workgroup
+template <int ENV, bool TLDS>
+__device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
+                                               float* action, int tree, bool live, int sub, int tl, unsigned gtree, float* obsT) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr int S = CONT ? 2 : 4;
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
+    st.path_D = 0; st.my_depth = -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
+    st.kbase = 1; st.eps_c = 0.0f;
+    if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
+        double rs[S], sn;
+#pragma unroll
+        for (int k = 0; k < S; ++k) rs[k] = live ? P.roots[(size_t)tree * S + k] : 0.0;
+        float obs[4];
+        env_obs<ENV>(rs, obs, &sn);
+        if (live && sub == 0) {
+            Rec h = make_edge<Rec>(0.0, 0);
+            h.node_n = (decltype(h.node_n))P.carry[tree];
+            h.flags = FLAG_EXPANDED;
+            clear_pad(h);
+            ts.hot[0] = h;
+            Cold c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c.s[k] = k < S ? rs[k] : 0.0;
+            if (CONT) c.s[2] = sn;
+            c.r = 0.0; c.V = 0.0f; c.mu = 0.0f; c.sg = 0.0f; c.pad = 0.0f;
+            cold[0] = c;
+            edge_W[0] = 0.0;
+            if (CONT) action[0] = 0.0f;
+        }
+        if (sub < 4) obsT[sub * 16 + tl] = live ? obs[sub] : 0.0f;
+}
+
+// Phase A: give the evaluated leaf its value / policy (evaluation, add_value_estimate: mcts.py:385-416, 602-623; the root's first
+// action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase.
+template <int ENV, bool TLDS, bool GMM, int NCH>
+__device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
+                                             float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
+                                             const float* bhead) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    typedef typename TreeStore<TLDS>::Id Id;
+    float V = 0.0f;
+    if (st.need_eval) {
+        V = head_output<NCH>(parts, bhead, tl, 0);
+        if (CONT) {
+            float mu, sg;
+            float gd[15];
+            if constexpr (GMM) {
+                gmm_params<NCH>(parts, bhead, tl, P.ncomp, P.ls_min, P.ls_max, gd);
+                mu = gd[0]; sg = gd[GMM_MAXC];
+                float* g = P.gmm + (tb + st.leaf) * 3 * GMM_MAXC;
+                if (sub == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3 * GMM_MAXC; ++i) g[i] = gd[i];
+                }
+            } else {
+                mu = head_output<NCH>(parts, bhead, tl, 1);
+                float ls = head_output<NCH>(parts, bhead, tl, 2);
+                ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
+                sg = azg_expf(ls);
+            }
+            if (sub == 0) { cold[st.leaf].V = V; cold[st.leaf].mu = mu; cold[st.leaf].sg = sg; }
+            if (sim < 0) {
+                // add_pw_action(root) before the first trace (mcts.py:673)
+                int k = st.nrec++;
+                if constexpr (GMM) gmm_pick(gd, P.ncomp, P.seed, gtree, P.search_idx, (unsigned)k, &mu, &sg);
+                float eps = __shfl(st.eps_c, k - st.kbase, 16);
+                float a = P.bound_f * azg_tanhf(mu + sg * eps);
+                if (sub == 0) {
+                    Rec h = make_edge<Rec>((double)V, 0);
+                    clear_pad(h);
+                    ts.hot[k] = h;
+                    edge_W[k] = 0.0;
+                    action[k] = a;
+                    ts.child[0] = (Id)k;
+                    ts.hot[0].n_child = 1;
+                }
+            }
+        } else {
+            // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
+            const int A = P.A;
+            float mx = head_output<NCH>(parts, bhead, tl, 1);
+            for (int a = 1; a < A; ++a) { float v = head_output<NCH>(parts, bhead, tl, 1 + a); mx = v > mx ? v : mx; }
+            float sum = 0.0f;
+            for (int a = 0; a < A; ++a) sum = sum + azg_expf(head_output<NCH>(parts, bhead, tl, 1 + a) - mx);
+            int k0 = st.nrec;
+            st.nrec += A;
+            if (sub < A) {
+                float prior_a = azg_expf(head_output<NCH>(parts, bhead, tl, 1 + sub) - mx) / sum;
+                Rec h = make_edge<Rec>((double)V, st.leaf);
+                clear_pad(h);
+                ts.hot[k0 + sub] = h;
+                ts.prior[k0 + sub] = prior_a;
+                edge_W[k0 + sub] = 0.0;
+            }
+            if (sub == 0) {
+                cold[st.leaf].V = V;
+                ts.hot[st.leaf].n_child = (decltype(ts.hot[st.leaf].n_child))A;
+                ts.hot[st.leaf].first = (decltype(ts.hot[st.leaf].first))k0;
+            }
+        }
+    }
+    if (sim >= 0) {
+        if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
+        backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW);
+    }
+}
+
+// Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
+// step the environment and create the node (expansion: mcts.py:216-238); leaves the new leaf's observation in obsT.
+template <int ENV, bool TLDS, bool GMM>
+__device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
+                                             float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
+                                             const int* s_pw, float* obsT) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr int S = CONT ? 2 : 4;
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    typedef typename TreeStore<TLDS>::Id Id;
+    st.need_eval = false;
+    if (CONT && st.nrec >= st.kbase + 16) {
+        st.kbase = st.nrec;
+        st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
+    }
+    int p = 0;
+    Rec hp = ts.hot[0];
+    Cold cp = cold[0];   // cold part of the current node, prefetched one level ahead
+    st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
+    int chosen = 0;
+    bool widen = false, hit_terminal = false;
+    while (true) {
+        const int K = hp.n_child;
+        if (CONT) {
+            int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
+            widen = s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
+            if (widen) break;
+        }
+        int pick = -1;
+        if (P.epsilon != 0.0) {
+            // MCTS.epsilon_greedy (mcts.py:190-195)
+            azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
+            if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
+        }
+        const double sq = s_sqrt[hp.node_n];
+        int win_c = 0;
+        if (K <= 16) {
+            // the common case: all children fit one 16-lane row
+            const bool valid = sub < K;
+            int c = 0;
+            double U = 0.0;
+            if (valid) {
+                c = CONT ? (int)ts.child[p * P.Kp + sub] : (int)hp.first + sub;
+                Rec h = ts.hot[c];
+                double ratio = sq / (double)((int)h.edge_n + 1);
+                if (CONT) {
+                    U = h.Q + P.c_uct * ratio;
+                } else {
+                    float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+                    U = h.Q + (double)pc * ratio;
+                }
+            }
+            if (pick >= 0) win_c = __shfl(c, pick, 16);
+            else win_c = argmax16_payload(U, valid, sub, c);
+        } else {
+            double win_u = 0.0;
+            bool have = false;
+            for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
+                const int i = base + sub;
+                const bool valid = i < K;
+                int c = 0;
+                double U = 0.0;
+                if (valid) {
+                    c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
+                    Rec h = ts.hot[c];
+                    double ratio = sq / (double)((int)h.edge_n + 1);
+                    if (CONT) {
+                        U = h.Q + P.c_uct * ratio;
+                    } else {
+                        float pc = ts.prior[c] * P.c_uct_f;
+                        U = h.Q + (double)pc * ratio;
+                    }
+                }
+                int w;
+                if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
+                else w = argmax16(U, valid, sub);
+                if (w >= 0) {
+                    int wc = __shfl(c, w, 16);
+                    double wu = __shfl(U, w, 16);
+                    if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
+                }
+            }
+        }
+        chosen = win_c;
+        Rec hc = ts.hot[chosen];
+        if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it
+        st.path_D += 1;
+        p = chosen;
+        hp = hc;
+        if (sub == (st.path_D & 15)) {   // only the slot's lane fetches the level's reward and W (used by backup_path)
+            st.my_depth = st.path_D; st.pid = chosen;
+            st.pr = cold[chosen].r; st.pW = edge_W[chosen];
+        }
+        if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
+        cp = cold[p];
+    }
+    if (hit_terminal) {
+        st.leaf = p;
+    } else {
+        float cact = 0.0f;
+        if (widen) {
+            // MCTSContinuous.add_pw_action (mcts.py:625-654)
+            const int K = hp.n_child;
+            chosen = st.nrec++;
+            float eps = __shfl(st.eps_c, chosen - st.kbase, 16);
+            float wmu = cp.mu, wsg = cp.sg;
+            if constexpr (GMM) {
+                float gd[15];
+                const float* g = P.gmm + (tb + p) * 3 * GMM_MAXC;
+#pragma unroll
+                for (int i = 0; i < 3 * GMM_MAXC; ++i) gd[i] = g[i];
+                gmm_pick(gd, P.ncomp, P.seed, gtree, P.search_idx, (unsigned)chosen, &wmu, &wsg);
+            }
+            cact = P.bound_f * azg_tanhf(wmu + wsg * eps);
+            if (sub == 0) {
+                Rec h = make_edge<Rec>((double)cp.V, p);
+                clear_pad(h);
+                ts.hot[chosen] = h;
+                edge_W[chosen] = 0.0;
+                action[chosen] = cact;
+                ts.child[p * P.Kp + K] = (Id)chosen;
+                ts.hot[p].n_child = (decltype(hp.n_child))(K + 1);
+            }
+        }
+        // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
+        st.path_D += 1;
+        double ns[S], r, sn;
+        int done;
+        if (CONT) {
+            if (!widen) cact = action[chosen];
+            pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
+            r = r / P.reward_scale;   // mcts.py:687
+        } else {
+            cartpole_step(cp.s, chosen - (int)hp.first, ns, &r, &done);
+        }
+        float obs[4];
+        env_obs<ENV>(ns, obs, &sn);
+        if (sub == 0) {
+            Cold c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c.s[k] = k < S ? ns[k] : 0.0;
+            if (CONT) c.s[2] = sn;
+            c.r = r; c.V = 0.0f; c.mu = 0.0f; c.sg = 0.0f; c.pad = 0.0f;
+            cold[chosen] = c;
+            ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+        }
+        if (sub == (st.path_D & 15)) { st.my_depth = st.path_D; st.pid = chosen; st.pr = r; st.pW = 0.0; }
+        st.leaf = chosen;
+        st.need_eval = !done;
+        if (sub < 4) obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
+    }
+}

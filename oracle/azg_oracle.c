@@ -233,11 +233,14 @@ static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
         float* t = x; x = h; h = t;
         kp = hp;
     }
-    int q = kp / 4;
+    /* head outputs: chunks of the (padded) hidden vector are chains from 0, the chunk partials are then added in order.
+     * HP <= 256: 4 chunks of HP/4 positions; wider layers: chunks of 64 positions */
+    int q = kp <= 256 ? kp / 4 : 64;
+    int nch = kp / q;
     for (int o = 0; o < m->n_out; ++o) {
         const float* w = m->Wh + (size_t)o * kp;
         float total = m->bh[o];
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < nch; ++c) {
             float p = 0.0f;
             for (int i = c * q; i < (c + 1) * q; ++i) { int k = perm_k(i); p = AZG_FMAF(w[k], x[k], p); }
             total = total + p;
