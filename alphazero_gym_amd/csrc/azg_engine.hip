@@ -28,6 +28,7 @@
 #include "tree.cuh"
 #include "search_kernel.cuh"
 #include "aux_kernels.cuh"
+#include "lockstep.cuh"
 
 // ------------------------------------------------------------------------------------------------ host side
 
@@ -52,6 +53,9 @@ struct azg_engine {
     uint32_t sp_step_idx;
     int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
     std::vector<void*> sp_allocs;
+    LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
+    std::vector<void*> ls_allocs;
+    int ls_hp;
     int searched, results_valid;
     float last_ms;
     std::string err;
@@ -146,6 +150,66 @@ static hipError_t dispatch(azg_engine* e) {
     return hipErrorInvalidValue;
 }
 
+// ---- lock-step path (wide networks): a few grid-wide launches per simulation step
+static int ls_prepare(azg_engine* e) {
+    if (e->ls_hp == e->HP) return AZG_OK;
+    for (void* p : e->ls_allocs) (void)hipFree(p);
+    e->ls_allocs.clear();
+    const size_t B = e->cfg.n_trees, G = (B + TREES_PER_WG - 1) / TREES_PER_WG, HP = e->HP;
+    float* obsT; float *a0, *a1, *parts; int* any; LsTree* tr; LsLane* ln;
+    if (dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
+        dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &any, G, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
+        dalloc(e, &ln, B * 16, e->ls_allocs))
+        return AZG_E_DEVICE;
+    e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts; e->ls.any = any;
+    e->ls.tree = tr; e->ls.lane = ln;
+    e->ls_hp = e->HP;
+    return AZG_OK;
+}
+
+template <int ENV, int HP, bool GMM>
+static hipError_t ls_run(azg_engine* e) {
+    constexpr int NS = HP / 256, NCH = HP / 64;
+    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG;
+    const size_t tab_bytes = ((size_t)e->tab_n * 8 + (size_t)(e->cfg.n_sims + 2) * 4 + 15) / 16 * 16;
+    const size_t act_bytes = (size_t)HP * 64;
+    auto tk = ls_tree_kernel<ENV, GMM, NCH>;
+    auto hk = ls_hidden_kernel<HP, false>;
+    auto hl = ls_hidden_kernel<HP, true>;
+    if (act_bytes > 48 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_bytes);
+        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)hl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_bytes);
+        if (rc != hipSuccess) return rc;
+    }
+    hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, -2);
+    for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
+        hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(G * NS), dim3(256), 0, e->stream, e->P, e->ls);
+        for (int l = 1; l < e->n_hidden; ++l) {
+            if (l == e->n_hidden - 1) hipLaunchKernelGGL(hl, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+            else hipLaunchKernelGGL(hk, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+        }
+        hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, sim);
+    }
+    return hipGetLastError();
+}
+
+template <int ENV>
+static hipError_t ls_dispatch(azg_engine* e) {
+    const bool gmm = ENV != AZG_ENV_CARTPOLE && e->P.ncomp >= 2;
+    if (e->HP == 512) {
+        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 512, true>(e); }
+        return ls_run<ENV, 512, false>(e);
+    }
+    if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 1024, true>(e); }
+    return ls_run<ENV, 1024, false>(e);
+}
+
+static bool use_lockstep(const azg_engine* e) {
+    const char* force = getenv("AZG_FORCE_PERSISTENT");
+    if (force && force[0] == '1') return false;
+    return e->HP >= 512 && e->n_hidden >= 2 && !e->P.layernorm;
+}
+
 extern "C" {
 
 int azg_abi_version(void) { return AZG_ABI_VERSION; }
@@ -159,6 +223,7 @@ void azg_engine_destroy(azg_engine* e) {
     for (void* p : e->dev_allocs) (void)hipFree(p);
     for (void* p : e->weight_allocs) (void)hipFree(p);
     for (void* p : e->sp_allocs) (void)hipFree(p);
+    for (void* p : e->ls_allocs) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -181,7 +246,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     azg_engine* e = new azg_engine();
     e->cfg = *cfg;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
-    e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0;
+    e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
     e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 3;
     const int ns = cfg->n_sims;
@@ -453,8 +518,12 @@ int azg_search_resident(azg_engine* e) {
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     e->P.search_idx = e->search_idx;
+    const bool lockstep = use_lockstep(e);
+    if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    hipError_t rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e) : dispatch<AZG_ENV_PENDULUM_V1>(e);
+    hipError_t rc;
+    if (lockstep) rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? ls_dispatch<AZG_ENV_CARTPOLE>(e) : ls_dispatch<AZG_ENV_PENDULUM_V1>(e);
+    else rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e) : dispatch<AZG_ENV_PENDULUM_V1>(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;

@@ -108,6 +108,7 @@ CONFIGS = [
     (1, 1, [64, 64], "elu", 40, dict(c_uct=0.2, gamma=0.95, c_pw=1.5, kappa=0.6, _ncomp=3)),
     # wide MLPs (BASELINE config E is 4x1024): weights streamed from L2, activation buffers up to 128 KB of LDS
     (2, 1, [512, 512], "elu", 30, dict(c_uct=0.05, gamma=1.0)),
+    (2, 1, [512, 512, 512], "elu", 20, dict(c_uct=0.05, gamma=1.0, _ncomp=2)),
     (2, 1, [1024, 1024, 1024, 1024], "elu", 12, dict(c_uct=0.05, gamma=1.0)),
     (0, 0, [512], "relu", 40, dict(c_uct=3.0, gamma=1.0, num_actions=2)),
     # trees too large for LDS residency (> 255 records): global-memory tree storage
@@ -117,7 +118,7 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the fallback code paths: weights streamed from L2 instead of registers, trees in global memory
@@ -130,6 +131,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
     if variant == "global_tree":
         monkeypatch.setenv("AZG_FORCE_GLOBAL_TREE", "1")
+    if variant == "persistent":
+        if max(hidden) <= 256:
+            pytest.skip("lock-step kernels only exist for hidden widths >= 512")
+        monkeypatch.setenv("AZG_FORCE_PERSISTENT", "1")   # wide networks: the one-launch kernel instead of the lock-step path
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
     in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else (4, 2)
