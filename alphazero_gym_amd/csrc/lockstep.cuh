@@ -107,31 +107,52 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
     const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
     if (!L.any[tg]) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const f32x4* in = L.act[in_buf] + (size_t)tg * S4 * 64;
-    for (int i = tid; i < S4 * 64; i += 256) s_in[i] = in[i];
-    __syncthreads();
     const f32x4* W = P.Wl[layer - 1];
     const f32x4* bb = P.bl[layer - 1];
     const int t0 = sl * 16 + wave * 4;   // this wave's 4 output tiles
-    f32x4 acc[4], a[4], an[4];
+    // weight stream: DEPTH k-blocks (4 tiles x 16 B per lane each) are kept in flight per wave -- with one block in flight the
+    // loop ran at L2 latency (29 GB/s per CU), not at the matrix pipe's rate
+    constexpr int DEPTH = 8;
+    static_assert(S4 % DEPTH == 0, "k-blocks per layer must be a multiple of the prefetch depth");
+    f32x4 q[DEPTH][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i] = bb[(t0 + i) * 64 + lane]; a[i] = W[((size_t)(t0 + i) * S4) * 64 + lane]; }
-#pragma unroll 2
-    for (int s4 = 0; s4 < S4; ++s4) {
-        const f32x4 b = s_in[s4 * 64 + lane];
-        const int sn = s4 + 1 < S4 ? s4 + 1 : s4;
+    for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) an[i] = W[((size_t)(t0 + i) * S4 + sn) * 64 + lane];   // next block's weights in flight
+        for (int i = 0; i < 4; ++i) q[d][i] = W[((size_t)(t0 + i) * S4 + d) * 64 + lane];
+    // stage the group's activations: all loads first (one round trip), then the LDS stores
+    const f32x4* in = L.act[in_buf] + (size_t)tg * S4 * 64;
+    constexpr int NST = S4 * 64 / 256;
+    f32x4 stg[NST];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+    for (int i = 0; i < NST; ++i) stg[i] = in[i * 256 + tid];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+    for (int i = 0; i < NST; ++i) s_in[i * 256 + tid] = stg[i];
+    __syncthreads();
+    f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) acc[i] = bb[(t0 + i) * 64 + lane];
+#pragma unroll 1
+    for (int s4 = 0; s4 < S4; s4 += DEPTH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+        for (int d = 0; d < DEPTH; ++d) {
+            const f32x4 b = s_in[(s4 + d) * 64 + lane];
+            f32x4 a[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = an[i];
+            for (int i = 0; i < 4; ++i) a[i] = q[d][i];
+            const int sn = s4 + d + DEPTH < S4 ? s4 + d + DEPTH : S4 - 1;   // (the tail re-reads the last block: harmless)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[d][i] = W[((size_t)(t0 + i) * S4 + sn) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep this block's loads here: the scheduler otherwise bunches all of an
+                                                 // iteration's loads at its end and the next iteration waits for them at once
+        }
     }
     f32x4 h[4];
 #pragma unroll
