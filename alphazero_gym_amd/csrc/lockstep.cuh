@@ -106,10 +106,11 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
     extern __shared__ f32x4 s_in[];   // the tree group's input activations: HP/16 tiles x 64 lanes
     const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
     if (!L.any[tg]) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const f32x4* W = P.Wl[layer - 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: weight addresses stay in SGPRs
     const f32x4* bb = P.bl[layer - 1];
     const int t0 = sl * 16 + wave * 4;   // this wave's 4 output tiles
+    const f32x4* W = P.Wl[layer - 1] + (size_t)t0 * S4 * 64 + lane;   // + (i * S4 + s4) * 64 with wave-uniform i, s4
     // weight stream: DEPTH k-blocks (4 tiles x 16 B per lane each) are kept in flight per wave -- with one block in flight the
     // loop ran at L2 latency (29 GB/s per CU), not at the matrix pipe's rate
     constexpr int DEPTH = 8;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[d][i] = W[((size_t)(t0 + i) * S4 + d) * 64 + lane];
+        for (int i = 0; i < 4; ++i) q[d][i] = W[(i * S4 + d) * 64];
     // stage the group's activations: all loads first (one round trip), then the LDS stores
     const f32x4* in = L.act[in_buf] + (size_t)tg * S4 * 64;
     constexpr int NST = S4 * 64 / 256;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
             for (int i = 0; i < 4; ++i) a[i] = q[d][i];
             const int sn = s4 + d + DEPTH < S4 ? s4 + d + DEPTH : S4 - 1;   // (the tail re-reads the last block: harmless)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[d][i] = W[((size_t)(t0 + i) * S4 + sn) * 64 + lane];
+            for (int i = 0; i < 4; ++i) q[d][i] = W[(i * S4 + sn) * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
 #pragma unroll
