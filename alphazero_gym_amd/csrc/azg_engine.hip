@@ -37,6 +37,7 @@ struct azg_engine {
     int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
     int mlp_ready, HP, n_hidden, n_out, act, nreg;
     int tree_lds;            // 1: hot records live in LDS during the search
+    int waves, groups, n_cus; // waves / 16-tree groups per workgroup of the last launch; compute units of the device
     size_t dyn_lds;          // dynamic LDS bytes per workgroup
     float ls_min, ls_max;
     hipStream_t stream;
@@ -84,46 +85,73 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
     return AZG_OK;
 }
 
-template <int ENV, int HP, int NREG, bool TLDS, bool GMM>
+// One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
+// Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
+template <int ENV, int HP, int NREG, bool TLDS, bool GMM, int NW, int NG>
 static hipError_t launch_g(azg_engine* e) {
-    dim3 grid((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG), block(256);
-    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM>;
-    if (e->dyn_lds > 48 * 1024) {
-        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->dyn_lds);
+    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
+    static int static_lds = -1;
+    if (static_lds < 0) {
+        hipFuncAttributes fa;
+        hipError_t rc = hipFuncGetAttributes(&fa, (const void*)kern);
+        if (rc != hipSuccess) return rc;
+        static_lds = (int)fa.sharedSizeBytes;
+    }
+    const LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, ENV != AZG_ENV_CARTPOLE, TLDS);
+    if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
+    if (L.total > 48 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (rc != hipSuccess) return rc;
     }
-    hipLaunchKernelGGL(kern, grid, block, e->dyn_lds, e->stream, e->P);
+    const int tpw = 16 * NG;
+    dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
+    e->tree_lds = TLDS ? 1 : 0;
+    e->dyn_lds = L.total;
+    e->waves = NW; e->groups = NG;
+    hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
     return hipGetLastError();
 }
 
-// LDS plan of one launch: tables + two activation buffers (+ the 16 trees' hot records when they fit: 8-bit record ids,
-// 16-bit counts, <= 16 children per node, and the 160 KB of a CU)
-static void plan_lds(azg_engine* e) {
-    const int ns = e->cfg.n_sims;
-    const bool cont = e->cfg.mode == AZG_MODE_CONTINUOUS;
-    size_t off = ((size_t)e->tab_n * 8 + (size_t)(ns + 2) * 4 + 15) / 16 * 16 + (size_t)2 * e->HP * 64;
-    size_t per = (size_t)e->R * 16 + (cont ? (size_t)e->R * e->Kp : (size_t)e->R * 4);
-    per = (per + 15) / 16 * 16;
-    const size_t static_lds = 4096 + 1024 + 256 + 64 + 64;   // head partials, outputs, observations, head bias (+ slack)
-    bool fits = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536 && off + per * TREES_PER_WG + static_lds <= 160 * 1024;
-    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
-    if (force && force[0] == '1') fits = false;
-    e->tree_lds = fits ? 1 : 0;
-    e->dyn_lds = fits ? off + per * TREES_PER_WG : off;
-}
-
-template <int ENV, int HP, int NREG, bool TLDS>
+template <int ENV, int HP, int NREG, bool TLDS, int NW, int NG>
 static hipError_t launch_t(azg_engine* e) {
-    if constexpr (ENV != AZG_ENV_CARTPOLE) {
-        if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true>(e);
+    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4) {
+        if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
     }
-    return launch_g<ENV, HP, NREG, TLDS, false>(e);
+    return launch_g<ENV, HP, NREG, TLDS, false, NW, NG>(e);
 }
 
+// Variant choice.  Trees live in LDS when they fit (8-bit record ids, 16-bit counts, <= 16 children per node, the CU's 160 KB).
+// While every 16-tree group can have a CU of its own, the 4-wave / 16-tree workgroup is the fastest shape (measured: the
+// 8-wave / 16-tree shape ties with it, the VALU work per SIMD being the same).  Once a batch has more groups than the device
+// has CUs, 2x256 Normal / 2-action networks run as 8-wave / 32-tree workgroups: two waves per SIMD, so one wave's tree walk
+// and activation math overlaps the other's MFMAs (1.27x at 8192 trees).  AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
 template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {
-    plan_lds(e);
-    return e->tree_lds ? launch_t<ENV, HP, NREG, true>(e) : launch_t<ENV, HP, NREG, false>(e);
+    const int ns = e->cfg.n_sims;
+    bool lds_ok = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536;
+    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
+    if (force && force[0] == '1') lds_ok = false;
+    if constexpr (HP == 256 && NREG == 1) {
+        const char* w = getenv("AZG_WAVES");
+        const char* g = getenv("AZG_GROUPS");
+        bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
+        if (g && g[0] == '2') two = true;
+        if (g && g[0] == '1') two = false;
+        bool want8 = two;
+        if (w && w[0] == '8') want8 = true;
+        if (w && w[0] == '4') want8 = false;
+        if (want8 && lds_ok && e->P.ncomp < 2) {
+            hipError_t rc = hipErrorInvalidConfiguration;
+            if (two) rc = launch_t<ENV, HP, NREG, true, 8, 2>(e);
+            if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, true, 8, 1>(e);
+            if (rc != hipErrorInvalidConfiguration) return rc;
+        }
+    }
+    if (lds_ok) {
+        hipError_t rc = launch_t<ENV, HP, NREG, true, 4, 1>(e);
+        if (rc != hipErrorInvalidConfiguration) return rc;
+    }
+    return launch_t<ENV, HP, NREG, false, 4, 1>(e);
 }
 
 template <int ENV>
@@ -275,6 +303,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->tree_lds = 0;
     e->dyn_lds = 0;
     if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
+    e->waves = 4; e->groups = 1; e->n_cus = 256;
+    (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
 #define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
     HK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));

@@ -64,19 +64,20 @@ __device__ __forceinline__ f32x4 mfma4(f32x4 a, f32x4 b, f32x4 acc) {
 }
 
 // Head outputs are summed in chunks of the hidden vector (chains from 0), the chunk partials then added in order:
-// HP <= 256: 4 chunks of HP/4 positions (one per wave); wider layers: chunks of 64 positions (4 tiles), HP/64 of them.
+// HP <= 256: 8 chunks of HP/8 positions; wider layers: chunks of 64 positions (4 tiles), HP/64 of them.
 template <int HP>
-__host__ __device__ constexpr int head_chunks() { return HP <= 256 ? 4 : HP / 64; }
+__host__ __device__ constexpr int head_chunks() { return HP <= 256 ? 8 : HP / 64; }
 
-// Register-resident hidden->hidden weights: wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer.
-template <int HP, int NREG>
+// Register-resident hidden->hidden weights.  A workgroup has NW waves (4: 16 trees, 8: 32 trees = two groups of 16);
+// wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer, for every tree group.
+template <int HP, int NREG, int NW = 4>
 struct WRegs {
-    static constexpr int NTW = HP / 64;
+    static constexpr int NTW = HP / (16 * NW);
     static constexpr int S4 = HP / 16;
     static constexpr int NW0 = HP <= 256 ? NTW : 1;   // first-layer weights are register-resident up to HP = 256
     f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
     f32x4 b[NREG > 0 ? NREG : 1][NTW];
-    f32x4 wh[NTW];   // head weights of this wave's K-chunk
+    f32x4 wh[NTW];   // head weights of this wave's K-chunk(s)
     float w0[NW0];   // first layer (K <= 4: one k-step per tile)
     f32x4 b0[NW0];
 };
@@ -125,36 +126,41 @@ __device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4
     }
 }
 
-// The MLP for the workgroup's 16 leaves.  obsT: [4][16] (input feature k, tree).  Result: parts[4 waves][64 lanes] = every
-// wave's partial head sums (head_output() combines them).  Activations cross waves through the two act buffers
-// (HP/16 tiles x 64 lanes x float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in
-// registers until the next layer publishes it, and the last layer's output feeds the head MFMAs directly.
-template <int HP, int NREG>
-__device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG>& wr, const float* obsT, f32x4* actA, f32x4* actB,
+// The MLP for the workgroup's leaves: NG groups of 16 trees, NW waves.  obsT: [4][16*NG] (input feature k, tree).  Result:
+// parts[group][chunk][PSTR] = the partial head sums (head_output() combines them; PSTR = 16 keeps only output rows 0..3,
+// enough for value + Normal / 2-action heads).  Activations cross waves through the act buffers ([group][HP/16 tiles][64 lanes]
+// float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in registers until the next layer
+// publishes it, and the last layer's output feeds the head MFMAs directly.
+template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64>
+__device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NREG, NW>& wr, const float* obsT, f32x4* actA, f32x4* actB,
                                             f32x4* parts, float* s_ln, int wave, int lane
 #ifdef AZG_STAMPS
                                             , unsigned long long* st_acc
 #endif
                                             ) {
     STAMP(m0);
-    constexpr int NTW = HP / 64;   // output tiles per wave
-    constexpr int S4 = HP / 16;    // groups of 4 MFMA k-steps over a hidden vector
-    f32x4 h[NTW];                  // this wave's tiles of the latest layer, after the activation
+    constexpr int NTW = HP / (16 * NW);    // output tiles per wave
+    constexpr int S4 = HP / 16;            // groups of 4 MFMA k-steps over a hidden vector
+    constexpr int ABUF = HP / 16 * 64;     // float4 entries of one group's activation buffer
+    constexpr int NCH = head_chunks<HP>();
+    static_assert(NW == 4 || NREG > 0, "the weight-streaming path is written for 4 waves");
+    f32x4 h[NG][NTW];                      // this wave's tiles of the latest layer, after the activation
     // layer 0: K = in_dim <= 4 -> one k-step
-    {
-        float b = obsT[lane];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float b = obsT[(lane >> 4) * (16 * NG) + g * 16 + (lane & 15)];
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             if constexpr (HP <= 256) {
-                h[i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
+                h[g][i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
             } else {   // wide layers: first-layer weights are not kept in registers
                 const int nt = wave * NTW + i;
-                h[i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0));
+                h[g][i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0));
             }
         }
-        // LayerNorm is compiled into the weight-streaming kernels only (the host selects them when layernorm is on)
-        if constexpr (NREG == 0) { if (P.layernorm) layer_norm_wg<HP>(P, 0, h, s_ln, wave, lane); }
     }
+    // LayerNorm is compiled into the weight-streaming kernels only (the host selects them when layernorm is on)
+    if constexpr (NREG == 0) { if (P.layernorm) layer_norm_wg<HP>(P, 0, h[0], s_ln, wave, lane); }
     f32x4* buf = actA;
     f32x4* other = actB;
     // hidden->hidden layers held in registers
@@ -162,32 +168,52 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
 #pragma unroll
         for (int l = 0; l < NREG; ++l) {
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) buf[g * ABUF + (wave * NTW + i) * 64 + lane] = h[g][i];
             __syncthreads();
             STAMP(m1);
-            f32x4 acc[NTW];
+            f32x4 acc[NG][NTW];
+            f32x4 bcur[NG], bnext[NG];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) acc[i] = wr.b[l][i];
-            f32x4 bcur = buf[lane];
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) acc[g][i] = wr.b[l][i];
+                bcur[g] = buf[g * ABUF + lane];
+            }
 #pragma unroll
             for (int s4 = 0; s4 < S4; ++s4) {
-                f32x4 bnext = bcur;
-                if (s4 + 1 < S4) bnext = buf[(s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    bnext[g] = bcur[g];
+                    if (s4 + 1 < S4) bnext[g] = buf[g * ABUF + (s4 + 1) * 64 + lane];   // prefetch the next 4 k-steps' B operand
+                }
                 __builtin_amdgcn_sched_barrier(0);                    // keep the ds_read above this block's MFMAs
-                // k-step outer, tile inner: consecutive MFMAs are independent chains (40-cycle dependent latency)
+                // k-step outer, (tile, group) inner: consecutive MFMAs are independent chains (40-cycle dependent latency)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].x, bcur.x, acc[i], 0, 0, 0);
+                for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].y, bcur.y, acc[i], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].x, bcur[g].x, acc[g][i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].z, bcur.z, acc[i], 0, 0, 0);
+                for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].w, bcur.w, acc[i], 0, 0, 0);
-                bcur = bnext;
+                    for (int g = 0; g < NG; ++g) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].y, bcur[g].y, acc[g][i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].z, bcur[g].z, acc[g][i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w[l][i][s4].w, bcur[g].w, acc[g][i], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) bcur[g] = bnext[g];
             }
             STAMP(m2);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) h[i] = act4<NREG == 0>(P.act, acc[i]);
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) h[g][i] = act4<NREG == 0>(P.act, acc[g][i]);
             STAMP(m2b);
             if (l == 0) { STAMP_ADD(4, m0, m1); }
             STAMP_ADD(5, m1, m2);
@@ -198,7 +224,7 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
         // weights streamed from global memory (L2-resident), any number of layers
         for (int l = 1; l < P.n_hidden; ++l) {
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[i];
+            for (int i = 0; i < NTW; ++i) buf[(wave * NTW + i) * 64 + lane] = h[0][i];
             __syncthreads();
             const f32x4* W = P.Wl[l - 1];
             const f32x4* bb = P.bl[l - 1];
@@ -225,39 +251,50 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WRegs<HP, NR
                     for (int i = 0; i < TG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < TG; ++i) h[tg + i] = act4<NREG == 0>(P.act, acc[i]);
+                for (int i = 0; i < TG; ++i) h[0][tg + i] = act4<NREG == 0>(P.act, acc[i]);
             }
-            if (P.layernorm) layer_norm_wg<HP>(P, l, h, s_ln, wave, lane);
+            if (P.layernorm) layer_norm_wg<HP>(P, l, h[0], s_ln, wave, lane);
             f32x4* t = buf; buf = other; other = t;
         }
     }
-    // heads: every chunk of the wave's hidden units is a chain from 0, straight from registers
+    // heads: every chunk of the wave's hidden units is a chain from 0, straight from registers; the wave's NSUB chunks
+    // (x NG groups) are independent chains, issued round-robin
     {
-        constexpr int NSUB = HP <= 256 ? 1 : NTW / 4;   // chunks per wave
-        constexpr int TPC = NTW / NSUB;                  // tiles per chunk
+        constexpr int NSUB = HP <= 256 ? 8 / NW : NTW / 4;   // chunks per wave
+        constexpr int KS = 4 * NTW / NSUB;                    // MFMA k-steps per chunk
+        f32x4 acc[NG][NSUB];
 #pragma unroll
-        for (int sc = 0; sc < NSUB; ++sc) {
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int i = 0; i < TPC; ++i) {
-                const int ti = sc * TPC + i;
-                f32x4 a = (NREG > 0) ? wr.wh[ti] : P.Whead[(wave * NTW + ti) * 64 + lane];
-                acc = mfma4(a, h[ti], acc);
+            for (int sc = 0; sc < NSUB; ++sc) acc[g][sc] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int sc = 0; sc < NSUB; ++sc) {
+                const int ks = sc * KS + j, ti = ks >> 2, cmp = ks & 3;
+                const f32x4 a = (NREG > 0) ? wr.wh[ti] : P.Whead[(wave * NTW + ti) * 64 + lane];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g][sc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cmp], h[g][ti][cmp], acc[g][sc], 0, 0, 0);
             }
-            parts[(wave * NSUB + sc) * 64 + lane] = acc;
         }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int sc = 0; sc < NSUB; ++sc)
+                if (PSTR == 64 || lane < 16) parts[(g * NCH + wave * NSUB + sc) * PSTR + lane] = acc[g][sc];
     }
     __syncthreads();
 }
 
-// network output o of tree tl: bias + the NCH chunk partials, added in chunk order (the oracle's summation order)
-template <int NCH>
+// network output o of a tree (column tl of its group of 16): bias + the NCH chunk partials, added in chunk order (the
+// oracle's summation order).  PSTR = 16: only outputs 0..3 were kept.
+template <int NCH, int PSTR = 64>
 __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_bhead, int tl, int o) {
     float total = s_bhead[o];
     const int idx = (o >> 2) * 16 + tl;
 #pragma unroll
     for (int w = 0; w < NCH; ++w) {
-        f32x4 pv = parts[w * 64 + idx];
+        f32x4 pv = parts[w * PSTR + idx];
         float p = (o & 3) == 0 ? pv.x : ((o & 3) == 1 ? pv.y : ((o & 3) == 2 ? pv.z : pv.w));
         total = total + p;
     }
@@ -268,25 +305,25 @@ __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_
 // DiagonalGMMPolicy head (policies.py:544-560) of one node from the raw network outputs: mu_c, sigma_c = exp(clamp(log_std_c)),
 // cumulative softmax(log_coeff) in component order.  d[15] = mu[5] | sigma[5] | cum[5] (fixed stride so that every index
 // below is a compile-time constant and the arrays stay in registers).
-template <int NCH>
+template <int NCH, int PSTR = 64>
 __device__ __forceinline__ void gmm_params(const f32x4* parts, const float* s_bhead, int tl, int C, float ls_min, float ls_max, float* d) {
-    float mx = head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C);
+    float mx = head_output<NCH, PSTR>(parts, s_bhead, tl, 1 + 2 * C);
 #pragma unroll
     for (int c = 1; c < GMM_MAXC; ++c)
-        if (c < C) { float v = head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
+        if (c < C) { float v = head_output<NCH, PSTR>(parts, s_bhead, tl, 1 + 2 * C + c); mx = v > mx ? v : mx; }
     float ex[GMM_MAXC], sum = 0.0f, cum = 0.0f;
 #pragma unroll
     for (int c = 0; c < GMM_MAXC; ++c) {
         ex[c] = 0.0f;
-        if (c < C) { ex[c] = azg_expf(head_output<NCH>(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
+        if (c < C) { ex[c] = azg_expf(head_output<NCH, PSTR>(parts, s_bhead, tl, 1 + 2 * C + c) - mx); sum = sum + ex[c]; }
     }
 #pragma unroll
     for (int c = 0; c < GMM_MAXC; ++c) {
         d[c] = 0.0f; d[GMM_MAXC + c] = 0.0f; d[2 * GMM_MAXC + c] = 2.0f;
         if (c < C) {
-            float ls = head_output<NCH>(parts, s_bhead, tl, 1 + C + c);
+            float ls = head_output<NCH, PSTR>(parts, s_bhead, tl, 1 + C + c);
             ls = ls < ls_min ? ls_min : (ls > ls_max ? ls_max : ls);
-            d[c] = head_output<NCH>(parts, s_bhead, tl, 1 + c);
+            d[c] = head_output<NCH, PSTR>(parts, s_bhead, tl, 1 + c);
             d[GMM_MAXC + c] = azg_expf(ls);
             cum = cum + ex[c] / sum;
             d[2 * GMM_MAXC + c] = cum;

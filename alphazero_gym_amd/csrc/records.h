@@ -13,17 +13,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Record j of a tree = edge j + (once expanded) the node that edge leads to; record 0 is the root.
 // "Hot" part: everything selection and the count/Q side of backup touch.  Two encodings:
-//   RecS (16 B) lives in LDS for the whole search when the tree fits (<= 255 records, counts < 65536),
+//   RecS (16 B) lives in LDS for the whole search when the tree fits (<= 255 records, counts < 65536, <= 16 children),
 //   RecL (24 B) lives in global memory (any size); it is also the format trees are published in at the end of a search.
+// Child lists of RecS nodes (continuous mode): child 0 is `first`; from the second child on the list lives in a per-tree
+// byte pool in LDS, in blocks of 4 / 8 / 16 ids at offset 4*cbase (a full block is copied into a fresh one of twice the size).
+// A node that ends with c children has used 0 (c <= 1), 1 (c <= 4), 3 (c <= 8) or 7 (c <= 16) four-byte units, i.e. at most
+// 7/9 of a unit per child, and a tree of R records has R-1 children in total: POOL_UNITS(R) units always suffice.
 struct __attribute__((aligned(16))) RecS {
     double Q;                // edge action value (Q_init = parent V)
     unsigned short edge_n;   // edge visit count
     unsigned short node_n;   // node visit count
     unsigned char parent;    // record of the parent node
-    unsigned char n_child;   // node: number of child edges
-    unsigned char flags;     // FLAG_EXPANDED | FLAG_TERMINAL
-    unsigned char first;     // discrete: record of child edge 0 (children are contiguous)
+    unsigned char n_child : 6;   // node: number of child edges (<= 16)
+    unsigned char flags : 2;     // FLAG_EXPANDED | FLAG_TERMINAL
+    unsigned char first;     // record of child edge 0 (discrete: the children are contiguous)
+    unsigned char cbase;     // continuous, n_child >= 2: the child list starts at pool[4 * cbase]
 };
+#define POOL_UNITS(R) ((7 * ((R) - 1) + 8) / 9 + 1)
 struct __attribute__((aligned(8))) RecL {
     double Q;
     int edge_n;

@@ -1,4 +1,9 @@
-// search_kernel.cuh -- the persistent search kernel: one launch = all n_sims traces of B trees (16 trees per workgroup).
+// search_kernel.cuh -- the persistent search kernel: one launch = all n_sims traces of B trees.  A workgroup of NW waves
+// owns NG groups of 16 trees (one 16-column MFMA tile each):
+//   NW = 4, NG = 1: one wave per SIMD, 4 trees per wave (any network);
+//   NW = 8, NG = 1: two waves per SIMD, 2 trees per wave: half the activation math and less tree-walk divergence per wave;
+//   NW = 8, NG = 2: two waves per SIMD, 32 trees: one wave's tree walk / activation math overlaps the other's MFMAs
+//                   (pays off when the batch has more 16-tree groups than the device has CUs).
 #pragma once
 #include "records.h"
 #include "env.cuh"
@@ -6,48 +11,69 @@
 #include "tree.cuh"
 #include "tree_phases.cuh"
 
-template <int ENV, int HP, int NREG, bool TLDS, bool GMM>
-__global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
+// Dynamic LDS layout of a workgroup, shared by the kernel and the host's launch planning
+struct LdsLayout {
+    size_t act_off;    // activation buffers: nbuf x NG groups x HP*64 bytes
+    size_t tree_off;   // (TLDS) per-tree regions
+    size_t per_tree;   // bytes per tree: R records of 16 B + child-list pool (continuous) or R priors (discrete)
+    size_t total;
+};
+__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, bool tlds) {
+    LdsLayout L;
+    L.act_off = ((size_t)tab_n * 8 + (size_t)(n_sims + 2) * 2 + 15) / 16 * 16;
+    L.tree_off = L.act_off + (size_t)nbuf * NG * HP * 64;
+    L.per_tree = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * 4 : (size_t)R * 4);
+    L.per_tree = (L.per_tree + 15) / 16 * 16;
+    L.total = L.tree_off + (tlds ? L.per_tree * 16 * NG : 0);
+    return L;
+}
+// activation buffers a kernel variant needs: one when a single register-resident hidden layer reads what layer 0 wrote
+__host__ __device__ constexpr int act_buffers(int NREG) { return NREG == 1 ? 1 : 2; }
+
+template <int ENV, int HP, int NREG, bool TLDS, bool GMM, int NW, int NG>
+__global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
-    constexpr int S = CONT ? 2 : 4;
+    constexpr int TPW = 16 * NG;        // trees per workgroup
+    constexpr int TPV = TPW / NW;       // trees per wave (16 lanes each; the wave's other lanes sit the tree phases out)
     typedef typename TreeStore<TLDS>::Rec Rec;
-    typedef typename TreeStore<TLDS>::Id Id;
     constexpr int NCH = head_chunks<HP>();   // partial head sums per tree
-    __shared__ f32x4 s_parts[NCH * 64];
-    __shared__ float s_obsT[4 * 16];
+    constexpr int PSTR = GMM ? 64 : 16;      // entries kept per chunk: all 16 output rows, or rows 0..3 (value + Normal / 2 actions)
+    __shared__ f32x4 s_parts[NG * NCH * PSTR];
+    __shared__ float s_obsT[4 * TPW];
     __shared__ float s_bhead[16];
-    __shared__ float s_ln[2 * 64];
-    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] ints, two activation buffers, (TLDS) the 16 trees' hot records
+    __shared__ float s_ln[NREG == 0 ? 2 * 64 : 1];
+    extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] u16, activation buffers, (TLDS) the trees' hot records
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int sub = lane & 15;
-    const int tl = wave * 4 + (lane >> 4);          // tree within the workgroup
-    const int tree = blockIdx.x * TREES_PER_WG + tl;
-    const bool live = tree < P.B;
+    const bool has_tree = (lane >> 4) < TPV;
+    const int tl = has_tree ? wave * TPV + (lane >> 4) : 0;   // tree within the workgroup
+    const int tree = blockIdx.x * TPW + tl;
+    const bool live = has_tree && tree < P.B;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
 
+    const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS);
     double* s_sqrt = s_dyn;
-    int* s_pw = (int*)(s_dyn + P.tab_n);
-    const size_t act_off = ((size_t)P.tab_n * 8 + (size_t)(P.n_sims + 2) * 4 + 15) / 16 * 16;
-    f32x4* s_actA = (f32x4*)((char*)s_dyn + act_off);
-    f32x4* s_actB = s_actA + HP / 16 * 64;
-    for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
-    if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
+    unsigned short* s_pw = (unsigned short*)(s_dyn + P.tab_n);   // widening thresholds, clamped (a node has < 32768 children)
+    f32x4* s_actA = (f32x4*)((char*)s_dyn + L.act_off);
+    f32x4* s_actB = act_buffers(NREG) == 2 ? s_actA + NG * (HP / 16 * 64) : s_actA;
+    for (int i = tid; i < P.tab_n; i += 64 * NW) s_sqrt[i] = P.sqrt_tab[i];
+    if (CONT) for (int i = tid; i < P.n_sims + 2; i += 64 * NW) s_pw[i] = (unsigned short)(P.pw_need[i] < 65535 ? P.pw_need[i] : 65535);
     if (tid < 16) s_bhead[tid] = P.bhead[tid];
 
     // register-resident weights
-    WRegs<HP, NREG> wr;
+    WRegs<HP, NREG, NW> wr;
+    constexpr int NTW = HP / (16 * NW);
     if constexpr (HP <= 256) {
-        constexpr int NTW0 = HP / 64;
 #pragma unroll
-        for (int i = 0; i < NTW0; ++i) {
-            wr.w0[i] = P.W0[(wave * NTW0 + i) * 64 + lane];
-            wr.b0[i] = P.b0[(wave * NTW0 + i) * 64 + lane];
+        for (int i = 0; i < NTW; ++i) {
+            wr.w0[i] = P.W0[(wave * NTW + i) * 64 + lane];
+            wr.b0[i] = P.b0[(wave * NTW + i) * 64 + lane];
         }
     }
     if (NREG > 0) {
-        constexpr int NTW = HP / 64, S4 = HP / 16;
+        constexpr int S4 = HP / 16;
 #pragma unroll
         for (int l = 0; l < NREG; ++l) {
 #pragma unroll
@@ -66,47 +92,46 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     double* edge_W = P.edge_W + tb;
     float* action = P.action + tb;
     TreeStore<TLDS> ts;
-    if (TLDS) {
-        // per tree: R records of 16 B, then (continuous) R x Kp child ids or (discrete) R priors
-        size_t off = act_off + (size_t)2 * HP * 64;
-        size_t per = (size_t)P.R * 16 + (CONT ? (size_t)P.R * P.Kp : (size_t)P.R * 4);
-        per = (per + 15) / 16 * 16;
-        char* base = (char*)s_dyn + off + per * tl;
+    if constexpr (TLDS) {
+        // per tree: R records of 16 B, then (continuous) the child-list pool or (discrete) R priors
+        char* base = (char*)s_dyn + L.tree_off + L.per_tree * tl;
         ts.hot = (Rec*)base;
-        ts.child = (Id*)(base + (size_t)P.R * 16);
+        ts.pool = (unsigned char*)(base + (size_t)P.R * 16);
         ts.prior = (float*)(base + (size_t)P.R * 16);
     } else {
         ts.hot = (Rec*)(P.hot + tb);
-        ts.child = (Id*)(P.child + tb * P.Kp);
+        ts.child = P.child + tb * P.Kp;
         ts.prior = P.prior + tb;
     }
+    const f32x4* my_parts = s_parts + (tl >> 4) * NCH * PSTR;   // the head partials of this tree's group
 
 #ifdef AZG_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    TreeState st;
-    tree_init_root<ENV, TLDS>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, s_obsT);
+    TreeState st = {};
+    st.need_eval = false;
+    if (has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, s_obsT);
     __syncthreads();
 
     for (int sim = -1; sim < P.n_sims; ++sim) {
-        // ================= network phase: evaluate the 16 pending leaves =================
+        // ================= network phase: evaluate the pending leaves =================
         STAMP(t_a);
         int any = __syncthreads_or(st.need_eval ? 1 : 0);
         STAMP(t_b);
 #ifdef AZG_STAMPS
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
+        if (any) mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
-        if (any) mlp_forward<HP, NREG>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
+        if (any) mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
         // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl, gtree, s_parts, s_bhead);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl & 15, gtree, my_parts, s_bhead);
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
         STAMP(t_d);
         // ================= tree phase B: next trace: select down, step the env, expand =================
         st.need_eval = false;
-        if (live) tree_phase_b<ENV, TLDS, GMM>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obsT);
+        if (live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obsT);
         __threadfence_block();
         STAMP(t_e);
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase
@@ -116,21 +141,21 @@ __global__ __launch_bounds__(256, 1) void search_kernel(KParams P) {
     }
     const int nrec = st.nrec;
 #ifdef AZG_STAMPS
-    if (lane == 0) for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * 4 + wave) * 16 + i] = st_acc[i];
+    if (lane == 0) for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * NW + wave) * 16 + i] = st_acc[i];
 #endif
     if (live) {
         if (sub == 0) P.n_rec[tree] = nrec;
-        if (TLDS) {
+        if constexpr (TLDS) {
             // publish the LDS-resident tree in the global format
             RecL* gh = P.hot + tb;
             for (int j = sub; j < nrec; j += 16) {
                 Rec h = ts.hot[j];
                 RecL o;
                 o.Q = h.Q; o.edge_n = h.edge_n; o.node_n = h.node_n; o.parent = (short)h.parent; o.n_child = h.n_child;
-                o.first = h.first; o.flags = h.flags; o.pad = 0;
+                o.first = CONT ? 0 : h.first; o.flags = h.flags; o.pad = 0;
                 gh[j] = o;
                 if (CONT) {
-                    for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = ts.child[j * P.Kp + i];
+                    for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = (unsigned short)ts.child_at(j, h, i, P.Kp);
                 } else {
                     P.prior[tb + j] = ts.prior[j];
                 }

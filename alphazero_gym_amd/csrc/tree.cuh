@@ -47,17 +47,43 @@ __device__ __forceinline__ int argmax16_payload(double u, bool valid, int sub, i
     return rowmin16((valid && u == m) ? ((sub << 16) | payload) : 0x7fffffff) & 0xffff;
 }
 
-// storage of the hot part of one tree: LDS (RecS, 8-bit ids) or global memory (RecL, 16-bit ids)
+// storage of the hot part of one tree: LDS (RecS, 8-bit ids, pooled child lists) or global memory (RecL, 16-bit ids,
+// a [Kp]-wide child table per record).  child_at / child_append are the continuous-mode child list accessors; the
+// arguments of child_append are uniform over the tree's 16 lanes and only `writer` (lane 0) stores.
 template <bool TLDS> struct TreeStore;
 template <> struct TreeStore<true> {
     typedef RecS Rec;
-    typedef unsigned char Id;
-    Rec* hot; Id* child; float* prior;
+    Rec* hot; unsigned char* pool; float* prior;
+    __device__ __forceinline__ int child_at(int, const Rec& hp, int i, int) const {
+        return hp.n_child == 1 ? (int)hp.first : (int)pool[4 * (int)hp.cbase + i];
+    }
+    __device__ __forceinline__ void child_append(int p, const Rec& hp, int K, int id, int& ptop, bool writer, int) const {
+        const int cb = hp.cbase;
+        if (K == 0) {
+            if (writer) hot[p].first = (unsigned char)id;
+        } else if (K == 1 || K == 4 || K == 8) {
+            const int nb = ptop;
+            ptop += K == 1 ? 1 : K / 2;   // blocks of 4, 8, 16 ids
+            if (writer) {
+                unsigned* pw = (unsigned*)pool;
+                if (K == 1) pool[4 * nb] = hp.first;
+                else for (int w = 0; w < K / 4; ++w) pw[nb + w] = pw[cb + w];
+                pool[4 * nb + K] = (unsigned char)id;
+                hot[p].cbase = (unsigned char)nb;
+            }
+        } else {
+            if (writer) pool[4 * cb + K] = (unsigned char)id;
+        }
+        if (writer) hot[p].n_child = (unsigned char)(K + 1);
+    }
 };
 template <> struct TreeStore<false> {
     typedef RecL Rec;
-    typedef unsigned short Id;
-    Rec* hot; Id* child; float* prior;
+    Rec* hot; unsigned short* child; float* prior;
+    __device__ __forceinline__ int child_at(int p, const Rec&, int i, int Kp) const { return (int)child[p * Kp + i]; }
+    __device__ __forceinline__ void child_append(int p, const Rec&, int K, int id, int&, bool writer, int Kp) const {
+        if (writer) { child[p * Kp + K] = (unsigned short)id; hot[p].n_child = (unsigned short)(K + 1); }
+    }
 };
 
 template <typename Rec>
@@ -66,7 +92,7 @@ __device__ __forceinline__ Rec make_edge(double Q, int parent) {
     h.Q = Q; h.edge_n = 0; h.node_n = 0; h.parent = (decltype(h.parent))parent; h.n_child = 0; h.flags = 0; h.first = 0;
     return h;
 }
-__device__ __forceinline__ void clear_pad(RecS&) {}
+__device__ __forceinline__ void clear_pad(RecS& h) { h.cbase = 0; }
 __device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
 
 // MCTS.backprop (mcts.py:260-267), generic part: walks parent links from record j to the root, 16 levels at a time

@@ -17,10 +17,12 @@ struct TreeState {
     double pr, pW;        // ... and that record's reward and cumulative return W (consumed by backup_path)
     int kbase;            // progressive-widening noise cache: lane `sub` holds the N(0,1) draw of record kbase + sub
     float eps_c;          // per lane
+    int ptop;             // LDS trees: next free 4-byte unit of the child-list pool
 };
 
-// initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][16] input block of the tree's workgroup
-template <int ENV, bool TLDS>
+// initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
+// workgroup (TPW trees per workgroup, tl = the tree's index in it)
+template <int ENV, bool TLDS, int TPW = 16>
 __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                                float* action, int tree, bool live, int sub, int tl, unsigned gtree, float* obsT) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
@@ -28,7 +30,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
     st.path_D = 0; st.my_depth = -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
-    st.kbase = 1; st.eps_c = 0.0f;
+    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0;
     if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
         double rs[S], sn;
 #pragma unroll
@@ -50,26 +52,26 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
             edge_W[0] = 0.0;
             if (CONT) action[0] = 0.0f;
         }
-        if (sub < 4) obsT[sub * 16 + tl] = live ? obs[sub] : 0.0f;
+        if (sub < 4) obsT[sub * TPW + tl] = live ? obs[sub] : 0.0f;
 }
 
 // Phase A: give the evaluated leaf its value / policy (evaluation, add_value_estimate: mcts.py:385-416, 602-623; the root's first
-// action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase.
-template <int ENV, bool TLDS, bool GMM, int NCH>
+// action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase
+// for the tree's group of 16 (PSTR entries per chunk), tl = the tree's column in that group.
+template <int ENV, bool TLDS, bool GMM, int NCH, int PSTR = 64>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
                                              const float* bhead) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     typedef typename TreeStore<TLDS>::Rec Rec;
-    typedef typename TreeStore<TLDS>::Id Id;
     float V = 0.0f;
     if (st.need_eval) {
-        V = head_output<NCH>(parts, bhead, tl, 0);
+        V = head_output<NCH, PSTR>(parts, bhead, tl, 0);
         if (CONT) {
             float mu, sg;
             float gd[15];
             if constexpr (GMM) {
-                gmm_params<NCH>(parts, bhead, tl, P.ncomp, P.ls_min, P.ls_max, gd);
+                gmm_params<NCH, PSTR>(parts, bhead, tl, P.ncomp, P.ls_min, P.ls_max, gd);
                 mu = gd[0]; sg = gd[GMM_MAXC];
                 float* g = P.gmm + (tb + st.leaf) * 3 * GMM_MAXC;
                 if (sub == 0) {
@@ -77,8 +79,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     for (int i = 0; i < 3 * GMM_MAXC; ++i) g[i] = gd[i];
                 }
             } else {
-                mu = head_output<NCH>(parts, bhead, tl, 1);
-                float ls = head_output<NCH>(parts, bhead, tl, 2);
+                mu = head_output<NCH, PSTR>(parts, bhead, tl, 1);
+                float ls = head_output<NCH, PSTR>(parts, bhead, tl, 2);
                 ls = ls < P.ls_min ? P.ls_min : (ls > P.ls_max ? P.ls_max : ls);
                 sg = azg_expf(ls);
             }
@@ -95,21 +97,20 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     ts.hot[k] = h;
                     edge_W[k] = 0.0;
                     action[k] = a;
-                    ts.child[0] = (Id)k;
-                    ts.hot[0].n_child = 1;
                 }
+                ts.child_append(0, make_edge<Rec>(0.0, 0), 0, k, st.ptop, sub == 0, P.Kp);
             }
         } else {
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
             const int A = P.A;
-            float mx = head_output<NCH>(parts, bhead, tl, 1);
-            for (int a = 1; a < A; ++a) { float v = head_output<NCH>(parts, bhead, tl, 1 + a); mx = v > mx ? v : mx; }
+            float mx = head_output<NCH, PSTR>(parts, bhead, tl, 1);
+            for (int a = 1; a < A; ++a) { float v = head_output<NCH, PSTR>(parts, bhead, tl, 1 + a); mx = v > mx ? v : mx; }
             float sum = 0.0f;
-            for (int a = 0; a < A; ++a) sum = sum + azg_expf(head_output<NCH>(parts, bhead, tl, 1 + a) - mx);
+            for (int a = 0; a < A; ++a) sum = sum + azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + a) - mx);
             int k0 = st.nrec;
             st.nrec += A;
             if (sub < A) {
-                float prior_a = azg_expf(head_output<NCH>(parts, bhead, tl, 1 + sub) - mx) / sum;
+                float prior_a = azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + sub) - mx) / sum;
                 Rec h = make_edge<Rec>((double)V, st.leaf);
                 clear_pad(h);
                 ts.hot[k0 + sub] = h;
@@ -131,14 +132,13 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 
 // Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
 // step the environment and create the node (expansion: mcts.py:216-238); leaves the new leaf's observation in obsT.
-template <int ENV, bool TLDS, bool GMM>
+template <int ENV, bool TLDS, bool GMM, int TPW = 16, typename PW = int>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
-                                             const int* s_pw, float* obsT) {
+                                             const PW* s_pw, float* obsT) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
-    typedef typename TreeStore<TLDS>::Id Id;
     st.need_eval = false;
     if (CONT && st.nrec >= st.kbase + 16) {
         st.kbase = st.nrec;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         const int K = hp.n_child;
         if (CONT) {
             int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
-            widen = s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
+            widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
             if (widen) break;
         }
         int pick = -1;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             int c = 0;
             double U = 0.0;
             if (valid) {
-                c = CONT ? (int)ts.child[p * P.Kp + sub] : (int)hp.first + sub;
+                c = CONT ? ts.child_at(p, hp, sub, P.Kp) : (int)hp.first + sub;
                 Rec h = ts.hot[c];
                 double ratio = sq / (double)((int)h.edge_n + 1);
                 if (CONT) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                 int c = 0;
                 double U = 0.0;
                 if (valid) {
-                    c = CONT ? (int)ts.child[p * P.Kp + i] : (int)hp.first + i;
+                    c = CONT ? ts.child_at(p, hp, i, P.Kp) : (int)hp.first + i;
                     Rec h = ts.hot[c];
                     double ratio = sq / (double)((int)h.edge_n + 1);
                     if (CONT) {
@@ -249,9 +249,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                 ts.hot[chosen] = h;
                 edge_W[chosen] = 0.0;
                 action[chosen] = cact;
-                ts.child[p * P.Kp + K] = (Id)chosen;
-                ts.hot[p].n_child = (decltype(hp.n_child))(K + 1);
             }
+            ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
         }
         // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
         st.path_D += 1;
@@ -278,6 +277,6 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (sub == (st.path_D & 15)) { st.my_depth = st.path_D; st.pid = chosen; st.pr = r; st.pW = 0.0; }
         st.leaf = chosen;
         st.need_eval = !done;
-        if (sub < 4) obsT[sub * 16 + tl] = done ? 0.0f : obs[sub];
+        if (sub < 4) obsT[sub * TPW + tl] = done ? 0.0f : obs[sub];
     }
 }

@@ -234,8 +234,8 @@ static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
         kp = hp;
     }
     /* head outputs: chunks of the (padded) hidden vector are chains from 0, the chunk partials are then added in order.
-     * HP <= 256: 4 chunks of HP/4 positions; wider layers: chunks of 64 positions */
-    int q = kp <= 256 ? kp / 4 : 64;
+     * HP <= 256: 8 chunks of HP/8 positions; wider layers: chunks of 64 positions */
+    int q = kp <= 256 ? kp / 8 : 64;
     int nch = kp / q;
     for (int o = 0; o < m->n_out; ++o) {
         const float* w = m->Wh + (size_t)o * kp;

@@ -114,15 +114,19 @@ CONFIGS = [
     # trees too large for LDS residency (> 255 records): global-memory tree storage
     (2, 1, [64, 64], "elu", 300, dict(c_uct=0.05, gamma=1.0)),
     (0, 0, [64, 64], "relu", 200, dict(c_uct=8.0, gamma=0.98, num_actions=2)),
+    # up to 16 children per node: the LDS child-list pool grows through all its block sizes (4, 8, 16)
+    (2, 1, [256, 256], "relu", 120, dict(c_uct=0.2, gamma=0.98, c_pw=1.4, kappa=0.5)),
+    (1, 1, [64, 64], "elu", 254, dict(c_uct=0.02, gamma=1.0, c_pw=1.0, kappa=0.5)),
 ]
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "waves8", "groups2"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
-    Variants force the fallback code paths: weights streamed from L2 instead of registers, trees in global memory
-    instead of LDS."""
+    Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
+    instead of LDS, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
+    itself only for batches of more 16-tree groups than CUs)."""
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
     ncomp = extra.pop("_ncomp", 0)
@@ -131,6 +135,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
     if variant == "global_tree":
         monkeypatch.setenv("AZG_FORCE_GLOBAL_TREE", "1")
+    if variant in ("waves8", "groups2"):
+        if hidden != [256, 256] or ln or ncomp:
+            pytest.skip("the 8-wave workgroups exist for 2x256 Normal / 2-action networks")
+        monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
     if variant == "persistent":
         if max(hidden) <= 256:
             pytest.skip("lock-step kernels only exist for hidden widths >= 512")
