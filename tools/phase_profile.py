@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where a simulation step spends its cycles (in-kernel s_memtime stamps, -DAZG_STAMPS build).
 Read the SHARES, not the absolute time (stamps serialise the schedule).  GPU box only:
-    make -C alphazero_gym_amd/csrc libazgym_hip_stamp.so && python tools/phase_profile.py"""
+    make -C alphazero_gym_amd/csrc libazgym_hip_stamp.so && python tools/phase_profile.py [pendulum|cartpole] [trees]"""
 import ctypes as C
 import os
 import sys
@@ -18,7 +18,7 @@ from alphazero_gym_amd import _capi, _native  # noqa: E402
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "pendulum"
-    B = 4096
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096   # > 4096 trees: the 8-wave / 32-tree workgroups
     if mode == "pendulum":
         n_sims, hidden = 200, [256, 256]
         e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=n_sims, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
