@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Batched self-play + training, end to end on one GPU: the scaled-out form of run_continuous.py:111-142 /
+run_discrete.py:94-122.  B games live on the device (azg_selfplay_*: search, final action, env step, resets, replay rows);
+every iteration downloads the new replay rows, runs the reference's loss / optimiser step in PyTorch on a random subset,
+and re-syncs the weights into the engine.
+
+    python examples/selfplay_train.py --game CartPole-v0 --games 512 --n-rollouts 32 --iters 30
+    python examples/selfplay_train.py --game Pendulum-v1 --games 512 --n-rollouts 50 --iters 40
+
+Prints the mean return of the episodes finished in each iteration (one JSON line per iteration)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from alphazero_gym_amd import run  # noqa: E402
+from alphazero_gym_amd.agent.agents import ContinuousAgent, DiscreteAgent  # noqa: E402
+
+
+def build_agent(game, hidden, n_rollouts, device, lr):
+    opt = dict(run.RMSPROP, lr=lr)
+    loss = dict(run.LOSS_TUNED, device=device)
+    if game.lower().startswith("pendulum"):
+        cfg = run.CONTINUOUS_DEFAULTS
+        policy = dict(cfg["policy"], hidden_dimensions=hidden, representation_dim=3, action_dim=1, action_bound=2.0)
+        mcts = dict(cfg["mcts"], n_rollouts=n_rollouts, device=device)
+        return ContinuousAgent(policy_cfg=policy, mcts_cfg=mcts, loss_cfg=loss, optimizer_cfg=opt, device=device, **cfg["agent"]), 3
+    cfg = run.DISCRETE_DEFAULTS
+    policy = dict(cfg["policy"], hidden_dimensions=hidden, representation_dim=4, action_dim=1, num_actions=2)
+    mcts = dict(cfg["mcts"], n_rollouts=n_rollouts, device=device, num_actions=2)
+    return DiscreteAgent(policy_cfg=policy, mcts_cfg=mcts, loss_cfg=loss, optimizer_cfg=opt, device=device, **cfg["agent"]), 4
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--game", default="CartPole-v0")
+    ap.add_argument("--games", type=int, default=512)
+    ap.add_argument("--n-rollouts", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--steps-per-iter", type=int, default=20)
+    ap.add_argument("--train-rows", type=int, default=2048, help="replay rows sampled per iteration")
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--hidden", type=int, nargs="+", default=[128, 128])
+    ap.add_argument("--max-episode-length", type=int, default=200)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--seed", type=int, default=34)
+    ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
+    return ap.parse_args(argv)
+
+
+def train(a, log=print):
+    """Runs the loop; returns the per-iteration records."""
+    torch.manual_seed(a.seed)
+    agent, state_dim = build_agent(a.game, a.hidden, a.n_rollouts, a.device, a.lr)
+    continuous = state_dim == 3
+    m = agent.mcts
+    sp = run.DeviceSelfPlay(agent.nn, game=a.game, n_games=a.games, n_rollouts=a.n_rollouts, c_uct=m.c_uct, gamma=m.gamma,
+                            epsilon=m.epsilon, c_pw=getattr(m, "c_pw", 1.0), kappa=getattr(m, "kappa", 0.5),
+                            max_episode_length=a.max_episode_length, capacity_steps=a.steps_per_iter, seed=a.seed)
+    K = sp.engine.kmax if continuous else 2
+    rng = np.random.RandomState(a.seed)
+    fs0, fc0 = 0.0, 0
+    t0 = time.time()
+    history = []
+    for it in range(a.iters):
+        rows = sp.collect(a.steps_per_iter)
+        pick = rng.choice(rows.shape[0], size=min(a.train_rows, rows.shape[0]), replace=False)
+        info = run.train_on_rows(agent, rows[torch.from_numpy(pick)], state_dim, K, batch_size=a.batch_size, shuffle_seed=it)
+        fsum, fcnt, _ = sp.engine.selfplay_stats()
+        fs, fc = float(fsum.sum()), int(fcnt.sum())
+        mean_ret = (fs - fs0) / max(fc - fc0, 1)
+        n_batches = max(1, len(pick) // a.batch_size)
+        history.append({"iter": it, "episodes_finished": fc - fc0, "mean_return": round(mean_ret, 2),
+                        "loss": round(info["loss"] / n_batches, 4), "env_steps": (it + 1) * a.steps_per_iter * a.games,
+                        "elapsed_s": round(time.time() - t0, 1)})
+        if log:
+            log(json.dumps(history[-1]), flush=True)
+        fs0, fc0 = fs, fc
+    return history
+
+
+def main():
+    train(parse_args())
+
+
+if __name__ == "__main__":
+    main()
