@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
         tree_init_root<ENV, false>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, obsT);
     } else {
         const LsTree t = L.tree[live ? tree : 0];
+#ifdef AZG_STAMPS
+        unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build: discarded here
+#endif
         const LsLane ln = L.lane[(size_t)(live ? tree : 0) * 16 + sub];
         st.nrec = t.nrec; st.eps_draws = t.eps_draws; st.leaf = t.leaf; st.need_eval = live && t.need_eval; st.path_D = t.path_D;
         st.kbase = t.kbase; st.my_depth = ln.my_depth; st.pid = ln.pid; st.pr = ln.pr; st.pW = ln.pW; st.eps_c = ln.eps_c;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
         st.need_eval = false;
         if (sim < P.n_sims - 1) {
             __threadfence_block();
-            if (live) tree_phase_b<ENV, false, GMM>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, obsT);
+            if (live) tree_phase_b<ENV, false, GMM>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, obsT STAMP_ARG);
             else if (sub < 4) obsT[sub * 16 + tl] = 0.0f;
         } else if (live && sub == 0) {
             P.n_rec[tree] = st.nrec;

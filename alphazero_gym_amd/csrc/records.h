@@ -91,7 +91,11 @@ struct KParams {
 #ifdef AZG_STAMPS
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#define STAMP_PARAM , unsigned long long* st_acc
+#define STAMP_ARG , st_acc
 #else
+#define STAMP_PARAM
+#define STAMP_ARG
 #define STAMP(var)
 #define STAMP_ADD(slot, t0, t1)
 #endif

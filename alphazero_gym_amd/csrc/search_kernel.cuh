@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
         STAMP(t_d);
         // ================= tree phase B: next trace: select down, step the env, expand =================
         st.need_eval = false;
-        if (live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obsT);
+        if (live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
         __threadfence_block();
         STAMP(t_e);
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase

@@ -41,10 +41,48 @@ __device__ __forceinline__ int argmax16(double u, bool valid, int sub) {
     double m = rowmax16(u, valid);
     return rowmin16((valid && u == m) ? sub : 99);
 }
-// same, but returns the payload (< 65536) of the winning lane: no second cross-lane round trip
+// 32-bit butterflies over the row: the compiler folds each DPP move into the min/max (v_max_i32_dpp ...), one VALU op per stage
+__device__ __forceinline__ int rowmax16_i32(int v) {
+    int o;
+    o = dpp_i32<DPP_QUAD_XOR1>(v); v = o > v ? o : v;
+    o = dpp_i32<DPP_QUAD_XOR2>(v); v = o > v ? o : v;
+    o = dpp_i32<DPP_ROW_ROR4>(v); v = o > v ? o : v;
+    o = dpp_i32<DPP_ROW_ROR8>(v); v = o > v ? o : v;
+    return v;
+}
+__device__ __forceinline__ unsigned rowmax16_u32(unsigned v) {
+    unsigned o;
+    o = (unsigned)dpp_i32<DPP_QUAD_XOR1>((int)v); v = o > v ? o : v;
+    o = (unsigned)dpp_i32<DPP_QUAD_XOR2>((int)v); v = o > v ? o : v;
+    o = (unsigned)dpp_i32<DPP_ROW_ROR4>((int)v); v = o > v ? o : v;
+    o = (unsigned)dpp_i32<DPP_ROW_ROR8>((int)v); v = o > v ? o : v;
+    return v;
+}
+// arg-max over the row that returns the payload (< 65536) of the winning lane, lowest lane on ties.  The float64 scores are
+// compared as order-preserving 64-bit integer keys, high word first (three 4-stage 32-bit butterflies instead of a 64-bit
+// compare-and-select per stage).  Scores are finite and never -0 (Q + c * ratio with ratio > 0), so key order == float order.
 __device__ __forceinline__ int argmax16_payload(double u, bool valid, int sub, int payload) {
-    double m = rowmax16(u, valid);
-    return rowmin16((valid && u == m) ? ((sub << 16) | payload) : 0x7fffffff) & 0xffff;
+    const long long bits = (long long)azg_d2u(u);
+    const long long key = bits ^ ((bits >> 63) & 0x7fffffffffffffffLL);
+    const int hi = valid ? (int)(key >> 32) : (int)0x80000000;
+    const unsigned lo = (unsigned)key;
+    const int mh = rowmax16_i32(hi);
+    const bool top = valid && hi == mh;
+    const unsigned ml = rowmax16_u32(top ? lo : 0u);
+    return rowmin16((top && lo == ml) ? ((sub << 16) | payload) : 0x7fffffff) & 0xffff;
+}
+
+// two candidates only (lanes 0 and 1 of the row; CartPole has two actions): one compare instead of a 16-lane butterfly.
+// Returns the winner's payload in every lane of the row, lane 0 on ties.
+#define DPP_QUAD_BCAST0 0x00   // quad_perm:[0,0,0,0]
+__device__ __forceinline__ int argmax2_payload(double u, int sub, int payload) {
+    const double o = dpp_f64<DPP_QUAD_XOR1>(u);
+    const int po = dpp_i32<DPP_QUAD_XOR1>(payload);
+    int w = (sub == 0) ? (u >= o ? payload : po) : 0;   // lane 0 decides: first index unless the second is strictly larger
+    w = dpp_i32<DPP_QUAD_BCAST0>(w);                     // lanes 0..3 hold the winner (a record id > 0), the other quads 0
+    int t = dpp_i32<DPP_ROW_ROR4>(w); w = t > w ? t : w; // spread by max over the rotations (whichever way they turn)
+    t = dpp_i32<DPP_ROW_ROR8>(w); w = t > w ? t : w;
+    return w;
 }
 
 // storage of the hot part of one tree: LDS (RecS, 8-bit ids, pooled child lists) or global memory (RecL, 16-bit ids,

@@ -135,7 +135,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 template <int ENV, bool TLDS, bool GMM, int TPW = 16, typename PW = int>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
-                                             const PW* s_pw, float* obsT) {
+                                             const PW* s_pw, float* obsT STAMP_PARAM) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
@@ -150,7 +150,9 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
     int chosen = 0;
     bool widen = false, hit_terminal = false;
+    STAMP(tb0);
     while (true) {
+        STAMP(tl0);
         const int K = hp.n_child;
         if (CONT) {
             int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
@@ -181,7 +183,13 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                     U = h.Q + (double)pc * ratio;
                 }
             }
+#ifdef AZG_STAMPS
+            U = U + 0.0 * (double)__shfl(c, 0, 16);   // consume the scores before the stamp
+#endif
+            STAMP(tl1);
+            STAMP_ADD(7, tl0, tl1);    // child records, priors, division, U
             if (pick >= 0) win_c = __shfl(c, pick, 16);
+            else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
             else win_c = argmax16_payload(U, valid, sub, c);
         } else {
             double win_u = 0.0;
@@ -213,8 +221,10 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             }
         }
         chosen = win_c;
+        STAMP(tl2);
         Rec hc = ts.hot[chosen];
         if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it
+        STAMP(tl3);
         st.path_D += 1;
         p = chosen;
         hp = hc;
@@ -224,7 +234,17 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         }
         if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
         cp = cold[p];
+        STAMP(tl4);
+        STAMP_ADD(8, tl0, tl2);    // whole selection of a level (scores + arg-max)
+        STAMP_ADD(9, tl2, tl3);    // chosen record
+        STAMP_ADD(10, tl3, tl4);   // path slot + cold prefetch issue
+        STAMP_ADD(11, tl0, tl4);   // full level
+#ifdef AZG_STAMPS
+        st_acc[12] += 1;
+#endif
     }
+    STAMP(tb1);
+    STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {
         st.leaf = p;
     } else {

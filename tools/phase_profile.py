@@ -44,15 +44,15 @@ def main():
         v = buf[:, i].astype(np.float64)
         print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
     print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
-    for i, nm in zip(range(4, 11), ["  mlp: layer0+ELU+publish", "  mlp: hidden MFMA loop", "  mlp: hidden act + store", "  (unused)",
-                                     "  A: finish leaf", "  B: descent", "  B: widen+env step+create"]):
-        v = buf[:, i].astype(np.float64)
-        print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
-    for i, nm in ((13, "  B: widen (cold wait+tanh)"), (14, "  B: env step + obs"), (15, "  B: store drain (fence)")):
+    for i, nm in ((4, "  mlp: layer0+ELU+publish"), (5, "  mlp: hidden MFMA loop"), (6, "  mlp: hidden act + store")):
         v = buf[:, i].astype(np.float64)
         print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
     b = buf.astype(np.float64)
-    print(f"  B: UCT level   {b[:, 11].sum() / max(b[:, 12].sum(), 1):8.0f} cycles each, {b[:, 12].mean() / (n_sims + 1):.2f} per step (wave-level: max over 4 trees)")
+    lv = max(b[:, 12].sum(), 1)
+    print(f"  B: whole descent           mean {b[:, 13].mean() / (n_sims + 1):9.0f} cycles/step, {b[:, 12].mean() / (n_sims + 1):.2f} completed levels per step "
+          f"(wave-level: max over the wave's trees)")
+    for i, nm in ((11, "full level"), (7, "child records + division + U"), (8, "scores + arg-max"), (9, "chosen record"), (10, "path slot + cold prefetch")):
+        print(f"  B: per level: {nm:30s} {b[:, i].sum() / lv:8.0f} cycles")
 
 
 if __name__ == "__main__":
