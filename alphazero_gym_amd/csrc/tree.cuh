@@ -2,6 +2,20 @@
 #pragma once
 #include "records.h"
 
+// n / d for the tree statistics (n finite, d a positive count, both far from the ends of the exponent range): the compiler's own
+// IEEE float64 division sequence (v_rcp_f64, two Newton steps, quotient, residual correction) without its operand scaling
+// and fix-up steps, which are no-ops for such operands -- the same correctly rounded quotient in 8 instead of 11 instructions
+__device__ __forceinline__ double tree_div(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = n * r;
+    double rem = __builtin_fma(-d, q, n);
+    return __builtin_fma(rem, r, q);
+}
+
 // ------------------------------------------------------------------------------------------------ tree walk (16 lanes per tree)
 
 // cross-lane moves inside a 16-lane row (one tree) on the DPP network: no LDS traffic, one VALU op each
@@ -17,6 +31,7 @@ __device__ __forceinline__ double dpp_f64(double v) {
 #define DPP_QUAD_XOR2 0x4E   // quad_perm:[2,3,0,1]
 #define DPP_ROW_ROR4 0x124
 #define DPP_ROW_ROR8 0x128
+#define DPP_ROW_ROR15 0x12F   // lane i reads lane (i + 1) & 15
 
 // maximum of u over the row (invalid lanes excluded)
 __device__ __forceinline__ double rowmax16(double u, bool valid) {
@@ -176,7 +191,7 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
             if (is_edge) {
                 int en = (int)mrec.edge_n + 1;
                 double Wn = W + myR;
-                mrec.Q = Wn / (double)en;
+                mrec.Q = tree_div(Wn, (double)en);
                 mrec.edge_n = (decltype(mrec.edge_n))en;
                 edge_W[mine] = Wn;
             }
@@ -197,14 +212,16 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
+    // the return travels down the path one lane per step on the DPP network: slot (depth & 15) reads its deeper neighbour's
+    // value (lane sub + 1, the slot of depth + 1) and adds its own reward -- the same serial chain, no LDS shuffles
 #pragma unroll 1
     for (int d = 0; d < n0; ++d) {
         const int src = (D - d) & 15;
-        double rd = __shfl(pr, src, 16);
-        double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * Rv;
-        Rv = rd + gR;
-        if (sub == src) myR = Rv;
+        const double nb = dpp_f64<DPP_ROW_ROR15>(myR);
+        const double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * nb;
+        if (sub == src) myR = pr + gR;
     }
+    if (D >= 16) Rv = __shfl(myR, (D - 15) & 15, 16);
     const bool valid = my_depth >= 0 && my_depth > D - 16;
     int par = 0;
     if (valid) {
@@ -213,7 +230,7 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
         if (my_depth >= 1) {
             int en = (int)rec.edge_n + 1;
             double Wn = pW + myR;
-            rec.Q = Wn / (double)en;
+            rec.Q = tree_div(Wn, (double)en);
             rec.edge_n = (decltype(rec.edge_n))en;
             edge_W[pid] = Wn;
         }

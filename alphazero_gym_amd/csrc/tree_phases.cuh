@@ -167,7 +167,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         }
         const double sq = s_sqrt[hp.node_n];
         int win_c = 0;
-        if (K <= 16) {
+        if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
             // the common case: all children fit one 16-lane row
             const bool valid = sub < K;
             int c = 0;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             if (valid) {
                 c = CONT ? ts.child_at(p, hp, sub, P.Kp) : (int)hp.first + sub;
                 Rec h = ts.hot[c];
-                double ratio = sq / (double)((int)h.edge_n + 1);
+                double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
                 if (CONT) {
                     U = h.Q + P.c_uct * ratio;
                 } else {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                 if (valid) {
                     c = CONT ? ts.child_at(p, hp, i, P.Kp) : (int)hp.first + i;
                     Rec h = ts.hot[c];
-                    double ratio = sq / (double)((int)h.edge_n + 1);
+                    double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
                     if (CONT) {
                         U = h.Q + P.c_uct * ratio;
                     } else {
@@ -233,7 +233,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             st.pr = cold[chosen].r; st.pW = edge_W[chosen];
         }
         if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
-        cp = cold[p];
+        if (CONT) cp = cold[p];   // Pendulum: a trace is 2-3 levels deep and the prefetch hides the one exposed global round trip;
+                                  // CartPole: 8-9 levels, issuing it at every level costs more than waiting once (measured)
         STAMP(tl4);
         STAMP_ADD(8, tl0, tl2);    // whole selection of a level (scores + arg-max)
         STAMP_ADD(9, tl2, tl3);    // chosen record
@@ -243,6 +244,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st_acc[12] += 1;
 #endif
     }
+    if (!CONT && p != 0 && !hit_terminal) cp = cold[p];
     STAMP(tb1);
     STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {
