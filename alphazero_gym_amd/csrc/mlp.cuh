@@ -8,16 +8,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // azg_expm1f on four values at once: the same operations in the same order per component (bit-identical), written
 // component-parallel so that the four dependent fma chains interleave (and pack into v_pk_fma_f32)
-__device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 x) {
-    // x <= 0 here, so only the lower clamp of azg_expm1f can trigger
-    const f32x4 lo = {-87.0f, -87.0f, -87.0f, -87.0f};
-    f32x4 xc = __builtin_elementwise_max(x, lo);
+__device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 xc) {
+    // -87 <= xc <= 0 here (act4 clamps), so neither clamp of azg_expm1f can trigger
     const f32x4 magic = {12582912.0f, 12582912.0f, 12582912.0f, 12582912.0f};
     const f32x4 l2e = {1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f, 1.44269504088896341f};
     const f32x4 ln2h = {0.693145751953125f, 0.693145751953125f, 0.693145751953125f, 0.693145751953125f};
     const f32x4 ln2l = {1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f, 1.42860682030941723212e-6f};
-    f32x4 kf = __builtin_elementwise_fma(xc, l2e, magic);
-    kf = kf - magic;
+    const f32x4 kb = __builtin_elementwise_fma(xc, l2e, magic);   // 1.5 * 2^23 + k: the integer k sits in the low mantissa bits
+    const f32x4 kf = kb - magic;
     f32x4 r = __builtin_elementwise_fma(-kf, ln2h, xc);
     r = __builtin_elementwise_fma(-kf, ln2l, r);
     f32x4 p = {1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f, 1.98412698412698413e-4f};
@@ -32,19 +30,22 @@ __device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 x) {
     p = __builtin_elementwise_fma(p, r, c2);
     p = __builtin_elementwise_fma(p, r, half);
     f32x4 em1 = __builtin_elementwise_fma(p * r, r, r);
-    i32x4 k = __builtin_convertvector(kf, i32x4);
-    f32x4 sc = (f32x4)((k + 127) << 23);
+    // 2^k = float bits (k + 127) << 23; the bits of kb are 0x4B400000 + k and 0x4B400000 << 23 == 0 (mod 2^32): one shift-add
+    const i32x4 scb = (((i32x4)kb) << 23) + 0x3F800000;
+    const f32x4 sc = (f32x4)scb;
     return __builtin_elementwise_fma(sc, em1, sc - one);
 }
 
-// ELU without a branch: max(x,0) + expm1(min(x,0)); expm1(+-0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit
-// for bit (the sign of a zero that v_max/v_min may pick differently from the host's select vanishes in the sum)
+// ELU without a branch: max(x,0) + expm1(clamp(x, -87, 0)); expm1(+-0) == +0 exactly, so this equals `x > 0 ? x : expm1(x)` bit
+// for bit (the sign of a zero that v_max / v_med3 may pick differently from the host's select vanishes in the sum)
 template <bool RARE = true>
 __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 pos = __builtin_elementwise_max(v, zero);
     if (act == AZG_ACT_ELU) {
-        f32x4 neg = __builtin_elementwise_min(v, zero);
+        f32x4 neg;
+        neg.x = __builtin_amdgcn_fmed3f(v.x, -87.0f, 0.0f); neg.y = __builtin_amdgcn_fmed3f(v.y, -87.0f, 0.0f);
+        neg.z = __builtin_amdgcn_fmed3f(v.z, -87.0f, 0.0f); neg.w = __builtin_amdgcn_fmed3f(v.w, -87.0f, 0.0f);
         return pos + expm1f4_nonpos(neg);
     }
     if (!RARE || act == AZG_ACT_RELU) return pos;
