@@ -14,10 +14,16 @@ name = sys.argv[2] if len(sys.argv) > 2 else tag
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+def newest(pattern):
+    """the most recent match (gpurun merges runs of the same tag into one directory)"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
+shutil.copy(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
 rows = []
 for d in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_insts"):
-    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    fs = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
     acc = collections.defaultdict(list)
