@@ -116,12 +116,14 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
     for (int sim = -1; sim < P.n_sims; ++sim) {
         // ================= network phase: evaluate the pending leaves =================
         STAMP(t_a);
-        int any = __syncthreads_or(st.need_eval ? 1 : 0);
+        // one barrier: the observations of phase B are visible.  The network runs even if every pending leaf of the workgroup is
+        // terminal (rare; its outputs are then ignored): testing for that costs two more barriers per step (__syncthreads_or)
+        __syncthreads();
         STAMP(t_b);
 #ifdef AZG_STAMPS
-        if (any) mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
+        mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
-        if (any) mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
+        mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
         // ================= tree phase A: finish the evaluated leaf, back up =================
