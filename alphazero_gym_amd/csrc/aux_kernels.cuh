@@ -180,3 +180,24 @@ __global__ void mfma_probe_kernel(const double* in, double* out, int K) {
     }
     if (lane == 0) out[0] = (double)acc.x;
 }
+
+// fn_id 101: matrix-pipe rate probe (diagnostic): every wave issues iters x 16 register-only fp32 MFMAs (4 independent chains);
+// out[0..1] of wave 0: shader-clock cycles (s_memtime) and constant 100 MHz ticks (s_memrealtime) across the loop.
+__global__ __launch_bounds__(256) void mfma_rate_kernel(double* out, int iters) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float a = 1.0f + 1e-7f * threadIdx.x, b = 1.0f - 1e-7f * threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = acc[0].x + acc[1].y + acc[2].z + acc[3].w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = (double)(t1 - t0); out[1] = (double)(r1 - r0); }
+    if (sum == 123.456f) out[2] = sum;   // keeps the chains alive
+}

@@ -183,7 +183,8 @@ static int ls_prepare(azg_engine* e) {
     if (e->ls_hp == e->HP) return AZG_OK;
     for (void* p : e->ls_allocs) (void)hipFree(p);
     e->ls_allocs.clear();
-    const size_t B = e->cfg.n_trees, G = (B + TREES_PER_WG - 1) / TREES_PER_WG, HP = e->HP;
+    // tree groups padded to a multiple of 4: the tiled layer kernel works on 4 groups per workgroup
+    const size_t B = e->cfg.n_trees, G = ((B + TREES_PER_WG - 1) / TREES_PER_WG + 3) / 4 * 4, HP = e->HP;
     float* obsT; float *a0, *a1, *parts; int* any; LsTree* tr; LsLane* ln;
     if (dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
         dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &any, G, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
@@ -191,6 +192,7 @@ static int ls_prepare(azg_engine* e) {
         return AZG_E_DEVICE;
     e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts; e->ls.any = any;
     e->ls.tree = tr; e->ls.lane = ln;
+    if (hipMemset(any, 0, G * sizeof(int)) != hipSuccess) return AZG_E_DEVICE;   // (the padding groups never need an evaluation)
     e->ls_hp = e->HP;
     return AZG_OK;
 }
@@ -209,12 +211,32 @@ static hipError_t ls_run(azg_engine* e) {
         if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)hl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_bytes);
         if (rc != hipSuccess) return rc;
     }
+    // hidden layers: the LDS-tiled kernel; AZG_LS_TILED=0 keeps the 16-tree x 256-unit weight-streaming kernel (diagnostics)
+    // (32 trees x 64 units per workgroup: two workgroups per CU at 1024 trees x 1024 units)
+    auto tkh = ls_hidden_tiled_kernel<HP, false, 2, 4>;
+    auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
+    const int TQ = (G + 1) / 2, NU = HP / 64;
+    const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
+    const char* tenv = getenv("AZG_LS_TILED");
+    const bool tiled = !(tenv && tenv[0] == '0');
+    if (tiled) {
+        hipError_t rc = hipFuncSetAttribute((const void*)tkh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
+        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
+        if (rc != hipSuccess) return rc;
+    }
     hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, -2);
     for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
         hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(G * NS), dim3(256), 0, e->stream, e->P, e->ls);
         for (int l = 1; l < e->n_hidden; ++l) {
-            if (l == e->n_hidden - 1) hipLaunchKernelGGL(hl, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
-            else hipLaunchKernelGGL(hk, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+            const bool last = l == e->n_hidden - 1;
+            if (tiled) {
+                if (last) hipLaunchKernelGGL(tkl, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
+                else hipLaunchKernelGGL(tkh, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
+            } else if (last) {
+                hipLaunchKernelGGL(hl, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+            } else {
+                hipLaunchKernelGGL(hk, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+            }
         }
         hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, sim);
     }
@@ -780,6 +802,21 @@ int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, s
         if (fn_id == 100) {
             int K = (int)((n - 1) / 2);
             hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, di, dout, K);
+        } else if (fn_id == 101 && n >= 8) {
+            // in = [workgroups, iterations, launches]; out = [cycles, 100 MHz ticks, -, ms per launch, TFLOP/s]
+            const int wgs = (int)in[0], iters = (int)in[1], reps = (int)in[2] > 0 ? (int)in[2] : 1;
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            hipLaunchKernelGGL(mfma_rate_kernel, dim3(wgs), dim3(256), 0, 0, dout, iters);
+            (void)hipEventRecord(e0, 0);
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_rate_kernel, dim3(wgs), dim3(256), 0, 0, dout, iters);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            double res[2] = {ms / reps, (double)wgs * 4 * iters * 16 * 2048.0 / (ms / reps * 1e-3) / 1e12};
+            (void)hipMemcpy(dout + 3, res, sizeof(res), hipMemcpyHostToDevice);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         } else {
             hipLaunchKernelGGL(math_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn_id, di, dout, n);
         }

@@ -3,9 +3,10 @@
 //   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand); trees and
 //                      the per-tree state live in global memory between launches
 //   ls_layer0_kernel   first layer for (tree group, 256-unit slice)
-//   ls_hidden_kernel   one hidden->hidden layer for (tree group, 256-unit slice): the group's activations are staged in LDS,
-//                      the slice's weights stream from L2 (blockIdx % 8 selects the XCD and blockIdx % NS the slice, so every
-//                      XCD's L2 holds exactly one 1 MB slice); the last layer also leaves the partial head sums
+//   ls_hidden_tiled_kernel   one hidden->hidden layer as an LDS-tiled GEMM, 32 trees x 64 units per workgroup, both operands
+//                      double-buffered through LDS, two workgroups per CU; the last layer also leaves the partial head sums
+//   ls_hidden_kernel   the earlier form of that layer (16 trees x 256 units, weights streamed from L2 into registers), kept
+//                      behind AZG_LS_TILED=0
 // The arithmetic (MFMA chains, chunked head sums) is the persistent kernel's, bit for bit.
 #pragma once
 #include "records.h"
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
     // loop ran at L2 latency (29 GB/s per CU), not at the matrix pipe's rate
     constexpr int DEPTH = 8;
     static_assert(S4 % DEPTH == 0, "k-blocks per layer must be a multiple of the prefetch depth");
+    f32x4 acc[4];   // bias first: loaded before everything that is still in flight inside the loop
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = bb[(t0 + i) * 64 + lane];
     f32x4 q[DEPTH][4];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
@@ -132,28 +136,28 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #pragma unroll
     for (int i = 0; i < NST; ++i) s_in[i * 256 + tid] = stg[i];
     __syncthreads();
-    f32x4 acc[4];
+    // the bias has to have arrived before the loop: a wait for it inside the loop would, from the second pass on, wait for the
+    // weight blocks in flight instead (waitcnt placement is static)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = bb[(t0 + i) * 64 + lane];
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i]));
 #pragma unroll 1
     for (int s4 = 0; s4 < S4; s4 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const f32x4 b = s_in[(s4 + d) * 64 + lane];
-            f32x4 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = q[d][i];
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].w, b.w, acc[i], 0, 0, 0);
+            // reload the same registers only after the MFMAs that read them: the new value's live range then does not overlap
+            // the old one's, the allocator keeps one register set and the loop has no copies (and no vmcnt(0)) at its end
             const int sn = s4 + d + DEPTH < S4 ? s4 + d + DEPTH : S4 - 1;   // (the tail re-reads the last block: harmless)
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[d][i] = W[(i * S4 + sn) * 64];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // keep this block's loads here: the scheduler otherwise bunches all of an
                                                  // iteration's loads at its end and the next iteration waits for them at once
         }
@@ -171,5 +175,146 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) hs = mfma4(P.Whead[(t0 + i) * 64 + lane], h[i], hs);
         L.parts[((size_t)tg * (HP / 64) + sl * 4 + wave) * 64 + lane] = hs;
+    }
+}
+
+// One hidden->hidden layer as an LDS-tiled GEMM: a workgroup owns TG tree groups x UT unit tiles.  Both operands stream through
+// LDS in chunks of LS_KC k-blocks (16 k each), double buffered, so that every weight block is read from L2 once per 16*TG trees
+// and every activation block once per 16*UT units, and the MFMAs are fed by ds_read_b128 only.  Each accumulator still runs
+// over k in ascending order: same arithmetic as everywhere else.
+// Buffers are padded to a multiple of 4 tree groups (the padding groups compute on whatever is there and are never read).
+// Measured on config E (1024 trees, 4x1024): 16x256 streaming kernel 26.5 us per layer; 64x64 tiles, one workgroup per CU 25 us;
+// 32x64 tiles, two workgroups per CU (one's barrier / LDS-refill bubbles under the other's MFMAs) 22 us; the register-only
+// MFMA loop of the same length is 16.5 us per launch (tools/mfma_rate.py).
+#ifndef LS_KC
+#define LS_KC 4
+#endif
+// Tile shape: TG tree groups x UT unit tiles per workgroup.  4 x 4 (one workgroup per CU at 1024 trees x 1024 units) or half
+// of that -- 4 x 2 or 2 x 4: twice the workgroups, two of them resident per CU, so that one's barrier / LDS-refill bubbles are
+// covered by the other's MFMAs.  The last layer keeps UT = 4: its 64 units are one head chunk (with TG = 2 the chunk's chain
+// passes from the wave that owns tiles 0-1 to the one that owns tiles 2-3 through LDS).
+template <int HP, bool LAST, int TG, int UT>
+__global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ) {
+    static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
+    static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
+    constexpr int WPG = 4 / TG;            // waves per tree group
+    constexpr int WT = UT / WPG;           // unit tiles per wave
+    constexpr int S4 = HP / 16, NU = HP / (16 * UT), KC = LS_KC, NCHUNK = S4 / KC;
+    static_assert(S4 % KC == 0, "k-blocks per layer must be a multiple of the chunk");
+    constexpr int ASZ = UT * KC * 64, BSZ = TG * KC * 64;   // float4 entries of a stage's A [UT tiles][KC][64] and B [TG groups][KC][64]
+    constexpr int STAGE = ASZ + BSZ;
+    constexpr int NLA = ASZ / 256, NLB = BSZ / 256;       // float4 loads per thread per chunk
+    static_assert(ASZ % 256 == 0 && BSZ % 256 == 0, "chunk does not divide over the workgroup");
+    extern __shared__ f32x4 s_ab[];                        // two stages
+    // blocks of one XCD (blockIdx % 8) share unit slices: every XCD's L2 holds NU/8 slices' weights
+    const int nb = TQ * NU;
+    int m = blockIdx.x;
+    if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
+    const int us = m / TQ, tq = m % TQ;
+    int anyv = 0;
+#pragma unroll
+    for (int i = 0; i < TG; ++i) anyv |= L.any[tq * TG + i];
+    if (!anyv) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = us * UT;                          // the UT output tiles
+    const int g0 = tq * TG;                          // the TG tree groups
+    const int wg = wave % TG, wt0 = (wave / TG) * WT;   // this wave: tree group g0 + wg, tiles t0 + wt0 .. + WT
+    const f32x4* W = P.Wl[layer - 1];
+    const f32x4* in = L.act[in_buf];
+    f32x4 ra[NLA], rb[NLB];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) {
+            const int e = j * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tile, offset in the tile's chunk
+            ra[j] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
+        }
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) {
+            const int e = j * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tree group, offset in the group's chunk
+            rb[j] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
+        }
+    };
+    auto store_chunk = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) s_ab[st * STAGE + j * 256 + tid] = ra[j];
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) s_ab[st * STAGE + ASZ + j * 256 + tid] = rb[j];
+    };
+    f32x4 acc[WT];   // bias first: store_chunk's wait for the chunk then covers it
+#pragma unroll
+    for (int i = 0; i < WT; ++i) acc[i] = P.bl[layer - 1][(t0 + wt0 + i) * 64 + lane];
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    // the bias has to have arrived before the loop: a wait for it inside the loop would, from the second pass on, wait for the
+    // next chunk's loads instead (waitcnt placement is static)
+#pragma unroll
+    for (int i = 0; i < WT; ++i) asm volatile("" : "+v"(acc[i]));
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; ++c) {
+        if (c + 1 < NCHUNK) load_chunk(c + 1);       // in flight under this chunk's MFMAs
+        const f32x4* sB = s_ab + (c & 1) * STAGE + ASZ + wg * KC * 64;
+        const f32x4* sA = s_ab + (c & 1) * STAGE + wt0 * KC * 64;
+        // operands of k-block s+1 are read from LDS while the MFMAs of k-block s run
+        f32x4 a[WT], b, an[WT], bn;
+        b = sB[lane];
+#pragma unroll
+        for (int i = 0; i < WT; ++i) a[i] = sA[(i * KC) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            if (s + 1 < KC) {
+                bn = sB[(s + 1) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) an[i] = sA[(i * KC + s + 1) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+            if (s + 1 < KC) {
+                b = bn;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) a[i] = an[i];
+            }
+        }
+        if (c + 1 < NCHUNK) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
+        __syncthreads();
+    }
+    f32x4 h[WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i) h[i] = act4<true>(P.act, acc[i]);
+    const int tg = g0 + wg;
+    if constexpr (!LAST) {
+        f32x4* out = L.act[in_buf ^ 1] + (size_t)tg * S4 * 64;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) out[(t0 + wt0 + i) * 64 + lane] = h[i];
+    } else {
+        // the slice's 64 units are one head chunk (chunk index = us): a chain from 0 over its 4 tiles, in tile order
+        f32x4 hs = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (WPG == 2) {
+            // tiles 0-1 live in waves 0..TG-1, tiles 2-3 in waves TG..3: the chain's running sum crosses through LDS
+            // (all MFMA reads of the stages are behind the loop's last barrier)
+            if (wt0 == 0) {
+#pragma unroll
+                for (int i = 0; i < WT; ++i) hs = mfma4(P.Whead[(t0 + i) * 64 + lane], h[i], hs);
+                s_ab[wg * 64 + lane] = hs;
+            }
+            __syncthreads();
+            if (wt0 != 0) {
+                hs = s_ab[wg * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) hs = mfma4(P.Whead[(t0 + wt0 + i) * 64 + lane], h[i], hs);
+                L.parts[((size_t)tg * NU + us) * 64 + lane] = hs;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs = mfma4(P.Whead[(t0 + i) * 64 + lane], h[i], hs);
+            L.parts[((size_t)tg * NU + us) * 64 + lane] = hs;
+        }
     }
 }
