@@ -205,3 +205,51 @@ def test_full_size_properties(native, B):
         np.testing.assert_array_equal(do["edge_W"][0], d["edge_W"][t])
         oo.close()
     e.close()
+
+
+def _random_case(rng):
+    """A random engine configuration + network: every mode, width class, activation, head and search parameter."""
+    cont = rng.random() < 0.5
+    n_hidden = int(rng.integers(1, 5))
+    width = int(rng.choice([24, 64, 100, 128, 200, 256]))
+    hidden = [width] * n_hidden if rng.random() < 0.7 else [int(rng.choice([48, 64, 128, 256])) for _ in range(n_hidden)]
+    act = str(rng.choice(["relu", "elu", "elu", "relu", "silu", "leakyrelu", "relu6", "hardswish"]))
+    ln = bool(rng.random() < 0.15)
+    n_sims = int(rng.choice([1, 2, 7, 33, 64, 120, 253, 254, 300]))
+    extra = dict(gamma=float(rng.choice([1.0, 0.99, 0.9])), epsilon=float(rng.choice([0.0, 0.0, 0.25])),
+                 v_target=str(rng.choice(["off_policy", "on_policy", "greedy"])))
+    ncomp = 0
+    if cont:
+        env = int(rng.choice([1, 2]))
+        extra.update(c_uct=float(rng.choice([0.02, 0.05, 0.5])), c_pw=float(rng.choice([0.5, 1.0, 1.13, 2.0, 4.0])),
+                     kappa=float(rng.choice([0.3, 0.5, 0.75])))
+        if rng.random() < 0.25:
+            ncomp = int(rng.integers(2, 6))
+        in_dim, n_dist = 3, (3 * ncomp if ncomp else 2)
+        mode = 1
+    else:
+        env, mode, in_dim, n_dist = 0, 0, 4, 2
+        extra.update(c_uct=float(rng.choice([1.5, 5.0, 30.0])), num_actions=2)
+    return env, mode, hidden, act, ln, n_sims, extra, ncomp, in_dim, n_dist
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
+    """Seeded random configurations (modes, widths, depths, activations, heads, widening laws, tree sizes on both sides of the
+    LDS limits, eps-greedy, value targets): every record of every tree identical to the oracle's."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    env, mode, hidden, act, ln, n_sims, extra, ncomp, in_dim, n_dist = _random_case(rng)
+    B = int(rng.choice([1, 5, 16, 19, 33]))
+    kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=int(rng.integers(1, 1 << 30)), tree_id_base=int(rng.integers(0, 1000)), **extra)
+    desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
+    blob = O.make_weights(int(rng.integers(1, 1000)), in_dim, hidden, n_dist, scale=float(rng.choice([1.0, 2.0, 3.0])))
+    if ln:
+        blob = O.add_layernorm(blob, in_dim, hidden, n_dist, 7)
+    o = O.OracleEngine(**kw)
+    roots = o.synthetic_roots()
+    o.close()
+    carry = np.minimum(np.arange(B) % 5, 3 * n_sims).astype(np.int32) if mode == 0 else None
+    sidx = int(rng.integers(0, 50))
+    a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=sidx)
+    b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=sidx)
+    _assert_same(a, b)
