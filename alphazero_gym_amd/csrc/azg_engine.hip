@@ -185,14 +185,15 @@ static int ls_prepare(azg_engine* e) {
     e->ls_allocs.clear();
     // tree groups padded to a multiple of 4: the tiled layer kernel works on 4 groups per workgroup
     const size_t B = e->cfg.n_trees, G = ((B + TREES_PER_WG - 1) / TREES_PER_WG + 3) / 4 * 4, HP = e->HP;
-    float* obsT; float *a0, *a1, *parts; int* any; LsTree* tr; LsLane* ln;
+    float* obsT; float *a0, *a1, *parts; LsTree* tr; LsLane* ln;
     if (dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
-        dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &any, G, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
+        dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
         dalloc(e, &ln, B * 16, e->ls_allocs))
         return AZG_E_DEVICE;
-    e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts; e->ls.any = any;
+    e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts;
     e->ls.tree = tr; e->ls.lane = ln;
-    if (hipMemset(any, 0, G * sizeof(int)) != hipSuccess) return AZG_E_DEVICE;   // (the padding groups never need an evaluation)
+    // the padding groups are computed like the others (their columns never mix with real ones): give them defined inputs
+    if (hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
     e->ls_hp = e->HP;
     return AZG_OK;
 }

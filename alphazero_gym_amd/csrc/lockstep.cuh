@@ -22,7 +22,6 @@ struct LockStep {
     float* obsT;        // [G][4][16]
     f32x4* act[2];      // [G][HP/16][64]   ping-pong activations (D-register layout)
     f32x4* parts;       // [G][HP/64][64]   partial head sums, one per 64-unit chunk
-    int* any;           // [G]              some tree of the group needs an evaluation this step
     LsTree* tree;       // [B]
     LsLane* lane;       // [B][16]
 };
@@ -84,15 +83,12 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
         ln.my_depth = st.my_depth; ln.pid = st.pid; ln.pr = st.pr; ln.pW = st.pW; ln.eps_c = st.eps_c; ln.pad = 0.0f;
         L.lane[(size_t)tree * 16 + sub] = ln;
     }
-    int any = __syncthreads_or(st.need_eval ? 1 : 0);
-    if (tid == 0) L.any[tg] = any;
 }
 
 template <int HP>
 __global__ __launch_bounds__(256) void ls_layer0_kernel(KParams P, LockStep L) {
     constexpr int NS = HP / 256;
     const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
-    if (!L.any[tg]) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float b = L.obsT[(size_t)tg * 64 + lane];
     f32x4* out = L.act[0] + (size_t)tg * (HP / 16) * 64;
@@ -109,7 +105,6 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
     constexpr int NS = HP / 256, S4 = HP / 16;
     extern __shared__ f32x4 s_in[];   // the tree group's input activations: HP/16 tiles x 64 lanes
     const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
-    if (!L.any[tg]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: weight addresses stay in SGPRs
     const f32x4* bb = P.bl[layer - 1];
@@ -211,10 +206,6 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     int m = blockIdx.x;
     if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
     const int us = m / TQ, tq = m % TQ;
-    int anyv = 0;
-#pragma unroll
-    for (int i = 0; i < TG; ++i) anyv |= L.any[tq * TG + i];
-    if (!anyv) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = us * UT;                          // the UT output tiles
     const int g0 = tq * TG;                          // the TG tree groups
