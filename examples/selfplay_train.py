@@ -7,7 +7,11 @@ and re-syncs the weights into the engine.
     python examples/selfplay_train.py --game CartPole-v0 --games 512 --n-rollouts 32 --iters 30
     python examples/selfplay_train.py --game Pendulum-v1 --games 512 --n-rollouts 50 --iters 40
 
-Prints the mean return of the episodes finished in each iteration (one JSON line per iteration)."""
+Prints the mean return of the episodes finished in each iteration (one JSON line per iteration).
+
+Multi-GPU (one process per GPU, RCCL):  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 \
+    examples/selfplay_train.py ...    Every rank plays --games games of its own (global game ids rank*games ...), the replay
+rows are all-gathered, rank 0 runs the optimiser step and broadcasts the weights (alphazero_gym_amd/distributed.py)."""
 import argparse
 import json
 import os
@@ -18,7 +22,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphazero_gym_amd import run  # noqa: E402
+from alphazero_gym_amd import distributed as D, run  # noqa: E402
 from alphazero_gym_amd.agent.agents import ContinuousAgent, DiscreteAgent  # noqa: E402
 
 
@@ -55,13 +59,17 @@ def parse_args(argv=None):
 
 def train(a, log=print):
     """Runs the loop; returns the per-iteration records."""
-    torch.manual_seed(a.seed)
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    torch.manual_seed(a.seed)   # same initial weights on every rank
     agent, state_dim = build_agent(a.game, a.hidden, a.n_rollouts, a.device, a.lr)
     continuous = state_dim == 3
     m = agent.mcts
     sp = run.DeviceSelfPlay(agent.nn, game=a.game, n_games=a.games, n_rollouts=a.n_rollouts, c_uct=m.c_uct, gamma=m.gamma,
                             epsilon=m.epsilon, c_pw=getattr(m, "c_pw", 1.0), kappa=getattr(m, "kappa", 0.5),
-                            max_episode_length=a.max_episode_length, capacity_steps=a.steps_per_iter, seed=a.seed)
+                            max_episode_length=a.max_episode_length, capacity_steps=a.steps_per_iter, seed=a.seed, rank=rank,
+                            device_id=torch.cuda.current_device() if a.device.startswith("cuda") else 0)
     K = sp.engine.kmax if continuous else 2
     rng = np.random.RandomState(a.seed)
     fs0, fc0 = 0.0, 0
@@ -69,23 +77,42 @@ def train(a, log=print):
     history = []
     for it in range(a.iters):
         rows = sp.collect(a.steps_per_iter)
+        if world > 1:
+            rows = D.gather_replay_rows(rows, device=a.device if a.device.startswith("cuda") else None)   # every rank's games
+            rows = rows.cpu()
+        info = {"loss": 0.0}
         pick = rng.choice(rows.shape[0], size=min(a.train_rows, rows.shape[0]), replace=False)
-        info = run.train_on_rows(agent, rows[torch.from_numpy(pick)], state_dim, K, batch_size=a.batch_size, shuffle_seed=it)
+        if rank == 0:
+            info = run.train_on_rows(agent, rows[torch.from_numpy(pick)], state_dim, K, batch_size=a.batch_size, shuffle_seed=it)
+        if world > 1:
+            D.broadcast_weights(agent.nn, src=0)
         fsum, fcnt, _ = sp.engine.selfplay_stats()
-        fs, fc = float(fsum.sum()), int(fcnt.sum())
+        stats = torch.tensor([float(fsum.sum()), float(fcnt.sum())], dtype=torch.float64)
+        if world > 1:
+            stats = stats.to(a.device if a.device.startswith("cuda") else "cpu")
+            dist.all_reduce(stats)
+        fs, fc = float(stats[0]), int(stats[1])
         mean_ret = (fs - fs0) / max(fc - fc0, 1)
         n_batches = max(1, len(pick) // a.batch_size)
         history.append({"iter": it, "episodes_finished": fc - fc0, "mean_return": round(mean_ret, 2),
-                        "loss": round(info["loss"] / n_batches, 4), "env_steps": (it + 1) * a.steps_per_iter * a.games,
+                        "loss": round(info["loss"] / n_batches, 4), "env_steps": (it + 1) * a.steps_per_iter * a.games * world,
                         "elapsed_s": round(time.time() - t0, 1)})
-        if log:
+        if log and rank == 0:
             log(json.dumps(history[-1]), flush=True)
         fs0, fc0 = fs, fc
     return history
 
 
 def main():
-    train(parse_args())
+    a = parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        if a.device.startswith("cuda"):
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group("gloo")
+    train(a)
 
 
 if __name__ == "__main__":

@@ -76,3 +76,51 @@ def test_two_rank_selfplay_equals_single_process():
     np.testing.assert_array_equal(rows, want)             # per-tree results do not depend on the number of ranks
     s_, a_, c_, q_, v_ = D.unpack_replay_rows(torch.from_numpy(rows), 2, r["actions"].shape[1])
     np.testing.assert_array_equal(c_.sum(1), np.full(B_TOTAL, N_SIMS))
+
+
+def _train_worker(rank, world, port, q):
+    """examples/selfplay_train.py in its multi-rank form (gloo here, RCCL on the GPU box), engine = the oracle test double"""
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from alphazero_gym_amd import _native
+    _native.HipEngine = O.OracleEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "selfplay_train.py")
+    spec = importlib.util.spec_from_file_location("selfplay_train", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = mod.parse_args(["--game", "CartPole-v0", "--games", "8", "--n-rollouts", "8", "--iters", "3", "--steps-per-iter", "6",
+                           "--train-rows", "64", "--batch-size", "16", "--hidden", "64", "64", "--device", "cpu"])
+    captured = {}
+    orig = mod.build_agent
+
+    def build(*a, **k):
+        agent, sd = orig(*a, **k)
+        captured["agent"] = agent
+        return agent, sd
+
+    mod.build_agent = build
+    hist = mod.train(args, log=None)
+    flat = torch.cat([p.detach().reshape(-1) for p in captured["agent"].nn.parameters()])
+    q.put((rank, hist, float(flat.double().sum()), float(flat.abs().double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_loop_keeps_weights_in_sync():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, h0, s0, a0), (_, h1, s1, a1) = got
+    assert s0 == s1 and a0 == a1 and np.isfinite(s0)                     # rank 0 trained, rank 1 received the same weights
+    assert len(h0) == 3 and h0[-1]["env_steps"] == 3 * 6 * 8 * 2         # both ranks' games counted
+    keys = ("iter", "episodes_finished", "mean_return", "env_steps")
+    assert [[h[k] for k in keys] for h in h0] == [[h[k] for k in keys] for h in h1]   # all-reduced episode statistics agree
+    assert sum(h["episodes_finished"] for h in h0) > 0
