@@ -34,6 +34,18 @@ def config_B():
     e.close()
 
 
+def config_ref():
+    """the reference's default continuous configuration (config/policy/ContinuousPolicy.yaml, config/mcts/MCTSContinuous.yaml):
+    3x128 ELU trunk, 2-component Gaussian mixture head, 25 rollouts -- batched over 4096 games"""
+    for ns in (25, 200):
+        e = _native.HipEngine(env_id=2, mode=1, n_trees=4096, n_sims=ns, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+        e.set_weights(_capi.make_desc(3, [128, 128, 128], 6, "elu", num_components=2), O.make_weights(34, 3, [128, 128, 128], 6))
+        e.upload_roots(e.synthetic_roots())
+        dt = timed(e, 10, 2)
+        print(f"reference default net (3x128 ELU, GMM-2), Pendulum 4096 trees x {ns} sims: {dt * 1e3:.3f} ms/search, {4096 * ns / dt:.3e} sims/s")
+        e.close()
+
+
 def config_E():
     B, NS = 1024, 200
     e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
@@ -82,4 +94,4 @@ def selfplay():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["B", "E", "pcie", "selfplay"]
     for w in which:
-        {"B": config_B, "E": config_E, "pcie": pcie, "selfplay": selfplay}[w]()
+        {"B": config_B, "E": config_E, "pcie": pcie, "selfplay": selfplay, "ref": config_ref}[w]()
