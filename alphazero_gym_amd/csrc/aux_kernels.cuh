@@ -201,3 +201,54 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(double* out, int iters) 
     if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = (double)(t1 - t0); out[1] = (double)(r1 - r0); }
     if (sum == 123.456f) out[2] = sum;   // keeps the chains alive
 }
+
+// fn_id 102: latency probe (diagnostic): one wave, dependent chains of N operations each; out[i] = shader cycles per operation.
+//   0 v_fma_f64   1 v_fma_f32   2 v_mul_f64 + v_add_f64   3 float64 division (tree_div)   4 IEEE float64 division
+//   5 LDS round trip (ds_read_b32, dependent address)   6 LDS 16-byte round trip   7 DPP move (dependent)   8 ds_bpermute
+//   9 global load round trip (dependent address, L2-resident)   10 azg_sincos   11 v_mfma_f32_16x16x4 dependent chain
+__global__ __launch_bounds__(64) void latency_probe_kernel(double* out, int* chase, int n) {
+    __shared__ int s_chase[1024];
+    __shared__ f32x4 s_wide[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 1024; i += 64) s_chase[i] = (i * 17 + 5) & 1023;
+    for (int i = lane; i < 256; i += 64) s_wide[i] = f32x4{(float)((i * 7 + 3) & 255), 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+    unsigned long long t0, t1;
+    double res[12];
+#define PROBE(idx, init, body, sink)                                              \
+    {                                                                             \
+        init;                                                                     \
+        __builtin_amdgcn_s_waitcnt(0);                                            \
+        t0 = __builtin_amdgcn_s_memtime();                                        \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        _Pragma("unroll 1") for (int it = 0; it < n; it += 8) { body; body; body; body; body; body; body; body; }   \
+        sink;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        t1 = __builtin_amdgcn_s_memtime();                                        \
+        res[idx] = (double)(t1 - t0) / n;                                         \
+    }
+    double xd = 1.0 + 1e-9 * lane, ad = 0.999999, bd = 1e-7, accd = 0.0;
+    float xf = 1.0f + 1e-6f * lane;
+    PROBE(0, , xd = __builtin_fma(xd, ad, bd), accd += xd)
+    PROBE(1, , xf = __builtin_fmaf(xf, 0.99999f, 1e-6f), accd += xf)
+    PROBE(2, , xd = xd * ad + bd, accd += xd)
+    PROBE(3, , xd = tree_div(xd + 2.0, 1.5), accd += xd)
+    PROBE(4, , xd = (xd + 2.0) / 1.5, accd += xd)
+    int p = lane;
+    PROBE(5, , p = s_chase[p], accd += p)
+    int pw = lane;
+    PROBE(6, , pw = (int)s_wide[pw & 255].x, accd += pw)
+    int dv = lane;
+    PROBE(7, , dv = __builtin_amdgcn_update_dpp(0, dv, 0x121, 0xf, 0xf, false) + 1, accd += dv)
+    int bv = lane;
+    PROBE(8, , bv = __builtin_amdgcn_ds_bpermute(((bv + 1) & 63) << 2, bv), accd += bv)
+    int g = lane;
+    PROBE(9, , g = chase[g], accd += g)
+    double sn = 0.1 * lane, cs = 0.0;
+    PROBE(10, , azg_sincos(sn + 0.5, &sn, &cs), accd += sn + cs)
+    f32x4 ma = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    PROBE(11, , ma = __builtin_amdgcn_mfma_f32_16x16x4f32(xf, 1.0f, ma, 0, 0, 0), accd += ma.x)
+#undef PROBE
+    if (lane == 0) for (int i = 0; i < 12; ++i) out[i] = res[i];
+    if (accd == 1.2345) out[12] = accd;
+}

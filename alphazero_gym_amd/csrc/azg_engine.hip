@@ -803,6 +803,17 @@ int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, s
         if (fn_id == 100) {
             int K = (int)((n - 1) / 2);
             hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, di, dout, K);
+        } else if (fn_id == 102 && n >= 16) {
+            // out[0..11] = shader cycles per dependent operation (see latency_probe_kernel)
+            int* chase = nullptr;
+            std::vector<int> hc(1 << 16);
+            for (size_t i = 0; i < hc.size(); ++i) hc[i] = (int)((i * 4099 + 77) & (hc.size() - 1));
+            if (hipMalloc((void**)&chase, hc.size() * 4) == hipSuccess) {
+                (void)hipMemcpy(chase, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+                hipLaunchKernelGGL(latency_probe_kernel, dim3(1), dim3(64), 0, 0, dout, chase, 4096);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(chase);
+            }
         } else if (fn_id == 101 && n >= 8) {
             // in = [workgroups, iterations, launches]; out = [cycles, 100 MHz ticks, -, ms per launch, TFLOP/s]
             const int wgs = (int)in[0], iters = (int)in[1], reps = (int)in[2] > 0 ? (int)in[2] : 1;
