@@ -5,24 +5,61 @@
 
 // ------------------------------------------------------------------------------------------------ result gathering
 
+// The root's child edges of one tree, staged per thread: every record (and action) is fetched by an independent load in an
+// unrolled loop -- one global round trip for all of them instead of one per child -- and then kept in LDS, where the
+// order-sensitive sums below can index it dynamically.  Trees with more than RK_MAX root children read global memory directly.
+#define RK_MAX 16
+#define RK_THREADS 64
+struct RootKids {
+    RecL rec[RK_MAX];
+    float act[RK_MAX];
+    int id[RK_MAX];
+};
+__device__ __forceinline__ void root_kids_load(const KParams& P, size_t tb, const RecL& root, bool cont, RootKids* k) {
+    const RecL* hot = P.hot + tb;
+    const unsigned short* child = P.child + tb * P.Kp;
+    const int nc = root.n_child;
+    int id[RK_MAX];
+#pragma unroll
+    for (int a = 0; a < RK_MAX; ++a) id[a] = a < nc ? (cont ? (int)child[a] : (int)root.first + a) : 0;
+    RecL r[RK_MAX];
+    float ac[RK_MAX];
+#pragma unroll
+    for (int a = 0; a < RK_MAX; ++a) { r[a] = hot[id[a]]; ac[a] = cont ? P.action[tb + id[a]] : (float)a; }
+#pragma unroll
+    for (int a = 0; a < RK_MAX; ++a) { k->rec[a] = r[a]; k->act[a] = ac[a]; k->id[a] = a < nc ? id[a] : -1; }
+}
+// child a of the root: from the staged copy, or from global memory for roots with more than RK_MAX children
+struct RootView {
+    const KParams& P; size_t tb; const RecL& root; bool cont; const RootKids* k; bool staged;
+    __device__ __forceinline__ int id(int a) const {
+        if (staged) return k->id[a];
+        return a < (int)root.n_child ? (cont ? (int)P.child[tb * P.Kp + a] : (int)root.first + a) : -1;
+    }
+    __device__ __forceinline__ RecL rec(int a) const { if (staged) return k->rec[a]; int i = id(a); return P.hot[tb + (i >= 0 ? i : 0)]; }
+    __device__ __forceinline__ float act(int a) const { if (staged) return k->act[a]; int i = id(a); return cont ? P.action[tb + (i >= 0 ? i : 0)] : (float)a; }
+};
+
 // MCTS.return_results (mcts.py:269-307): one thread per tree, from the published (global) trees
-__global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt, int* nch,
-                               int* child_n, double* child_state, float* root_V, float* root_dist) {
+__global__ __launch_bounds__(RK_THREADS) void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt,
+                                                           int* nch, int* child_n, double* child_state, float* root_V, float* root_dist) {
+    __shared__ RootKids s_kids[RK_THREADS];
     int tree = blockIdx.x * blockDim.x + threadIdx.x;
     if (tree >= P.B) return;
     size_t tb = (size_t)tree * P.R;
-    const RecL* hot = P.hot + tb;
-    const unsigned short* child = P.child + tb * P.Kp;
     const bool cont = P.mode == AZG_MODE_CONTINUOUS;
-    const RecL root = hot[0];
-    int nc = root.n_child;
+    const RecL root = P.hot[tb];
+    const int nc = root.n_child;
+    const bool staged = Kmax <= RK_MAX;
+    if (staged) root_kids_load(P, tb, root, cont, &s_kids[threadIdx.x]);
+    const RootView rv{P, tb, root, cont, &s_kids[threadIdx.x], staged};
     long tot = 0;
-    for (int a = 0; a < nc; ++a) tot += hot[cont ? child[a] : root.first + a].edge_n;
+    for (int a = 0; a < nc; ++a) tot += rv.rec(a).edge_n;
     double qmax = 0.0, onp = 0.0;
     for (int a = 0; a < Kmax; ++a) {
-        int k = a < nc ? (cont ? (int)child[a] : (int)root.first + a) : -1;
-        RecL h = hot[k >= 0 ? k : 0];
-        actions[(size_t)tree * Kmax + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
+        const int k = a < nc ? rv.id(a) : -1;
+        const RecL h = rv.rec(a < nc ? a : 0);
+        actions[(size_t)tree * Kmax + a] = k >= 0 ? rv.act(a) : 0.0f;
         counts[(size_t)tree * Kmax + a] = k >= 0 ? h.edge_n : 0;
         Q[(size_t)tree * Kmax + a] = k >= 0 ? h.Q : 0.0;
         bool ex = k >= 0 && (h.flags & FLAG_EXPANDED);
@@ -36,7 +73,7 @@ __global__ void results_kernel(KParams P, int Kmax, int v_target, float* actions
     if (cont) {
         // reference quirk (mcts.py:111 with Q of shape (K,1)): the K x K outer product is summed
         for (int a = 0; a < nc; ++a)
-            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+            for (int b = 0; b < nc; ++b) onp += ((double)rv.rec(b).edge_n / (double)tot) * rv.rec(a).Q;
     }
     vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
     nch[tree] = nc;
@@ -64,12 +101,12 @@ struct SelfPlay {
     double* roots; int* carry;
 };
 
-__global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
+__global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
+    __shared__ RootKids s_kids[RK_THREADS];
     int tree = blockIdx.x * blockDim.x + threadIdx.x;
     if (tree >= P.B) return;
     const size_t tb = (size_t)tree * P.R;
     const RecL* hot = P.hot + tb;
-    const unsigned short* child = P.child + tb * P.Kp;
     const bool cont = P.mode == AZG_MODE_CONTINUOUS;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
     const int S = P.S, K = Kmax, RL = S_obs + 3 * Kmax + 1;
@@ -78,6 +115,9 @@ __global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, 
     float* row = sp.rows + (size_t)tree * RL;
     const RecL r0 = hot[0];
     const int nc = r0.n_child;
+    const bool staged = Kmax <= RK_MAX;
+    if (staged) root_kids_load(P, tb, r0, cont, &s_kids[threadIdx.x]);
+    const RootView rv{P, tb, r0, cont, &s_kids[threadIdx.x], staged};
     float obs[4];
     double sn;
     if (env_id == AZG_ENV_CARTPOLE) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
@@ -85,11 +125,11 @@ __global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, 
     double qmax = 0.0, onp = 0.0;
     long tot = 0;
     int cmax = 0, amax = 0;
-    for (int a = 0; a < nc; ++a) tot += hot[cont ? (int)child[a] : (int)r0.first + a].edge_n;
+    for (int a = 0; a < nc; ++a) tot += rv.rec(a).edge_n;
     for (int a = 0; a < K; ++a) {
-        int k = a < nc ? (cont ? (int)child[a] : (int)r0.first + a) : -1;
-        RecL h = hot[k >= 0 ? k : 0];
-        row[S_obs + a] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
+        int k = a < nc ? rv.id(a) : -1;
+        RecL h = rv.rec(a < nc ? a : 0);
+        row[S_obs + a] = k >= 0 ? rv.act(a) : 0.0f;
         row[S_obs + K + a] = k >= 0 ? (float)h.edge_n : 0.0f;
         row[S_obs + 2 * K + a] = k >= 0 ? (float)h.Q : 0.0f;
         if (k >= 0) {
@@ -100,22 +140,21 @@ __global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, 
     }
     if (cont)
         for (int a = 0; a < nc; ++a)
-            for (int b = 0; b < nc; ++b) onp += ((double)hot[child[b]].edge_n / (double)tot) * hot[child[a]].Q;
+            for (int b = 0; b < nc; ++b) onp += ((double)rv.rec(b).edge_n / (double)tot) * rv.rec(a).Q;
     row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
     int pick = amax;
     if (!cont && !sp.deterministic) {
         azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
         double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
         double sum = 0.0;
-        for (int a = 0; a < nc; ++a) sum = sum + (double)hot[(int)r0.first + a].edge_n / (double)cmax;
+        for (int a = 0; a < nc; ++a) sum = sum + (double)rv.rec(a).edge_n / (double)cmax;
         double cum = 0.0;
         pick = nc - 1;
         for (int a = 0; a < nc; ++a) {
-            cum = cum + ((double)hot[(int)r0.first + a].edge_n / (double)cmax) / sum;
+            cum = cum + ((double)rv.rec(a).edge_n / (double)cmax) / sum;
             if (u < cum) { pick = a; break; }
         }
     }
-    const int krec = cont ? (int)child[pick] : (int)r0.first + pick;
     double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
     int done;
     if (env_id == AZG_ENV_CARTPOLE) {
@@ -123,7 +162,7 @@ __global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, 
     } else {
         double s1, c1;
         azg_sincos(root[0], &s1, &c1);
-        pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, s1, P.action[tb + krec], ns, &r, &done);
+        pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, s1, rv.act(pick), ns, &r, &done);
     }
     double ret = sp.ret[tree] + r;
     int t = sp.t[tree] + 1;
@@ -137,7 +176,7 @@ __global__ void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, 
         azg_reset_state(P.seed, gtree, (unsigned)ep, env_id == AZG_ENV_CARTPOLE, ns);
         sp.carry[tree] = 0;
     } else {
-        RecL hk = hot[krec];
+        RecL hk = rv.rec(pick);
         sp.carry[tree] = (!cont && (hk.flags & FLAG_EXPANDED)) ? hk.node_n : 0;
     }
     sp.ret[tree] = ret;

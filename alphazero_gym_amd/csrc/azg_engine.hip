@@ -614,7 +614,7 @@ static int gather_results(azg_engine* e) {
     if (e->results_valid) return AZG_OK;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     int B = e->cfg.n_trees;
-    hipLaunchKernelGGL(results_kernel, dim3((B + 127) / 128), dim3(128), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
+    hipLaunchKernelGGL(results_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
                        e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -760,7 +760,7 @@ int azg_selfplay_step(azg_engine* e) {
     sp.rows = e->d_sp_rows + (size_t)e->sp_steps * e->cfg.n_trees * e->sp_row;
     sp.roots = e->d_roots; sp.carry = e->d_carry;
     const int B = e->cfg.n_trees;
-    hipLaunchKernelGGL(selfplay_kernel, dim3((B + 127) / 128), dim3(128), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
+    hipLaunchKernelGGL(selfplay_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
     HIPCHK(e, hipGetLastError());
     e->sp_steps += 1;
     e->sp_step_idx += 1;
