@@ -36,7 +36,7 @@ struct azg_engine {
     azg_config cfg;
     int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
     int mlp_ready, HP, n_hidden, n_out, act, nreg;
-    int tree_lds;            // 1: hot records live in LDS during the search
+    int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
     int waves, groups, n_cus; // waves / 16-tree groups per workgroup of the last launch; compute units of the device
     size_t dyn_lds;          // dynamic LDS bytes per workgroup
     float ls_min, ls_max;
@@ -87,7 +87,7 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
 
 // One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
 // Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
-template <int ENV, int HP, int NREG, bool TLDS, bool GMM, int NW, int NG>
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
 static hipError_t launch_g(azg_engine* e) {
     auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
     static int static_lds = -1;
@@ -105,14 +105,14 @@ static hipError_t launch_g(azg_engine* e) {
     }
     const int tpw = 16 * NG;
     dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
-    e->tree_lds = TLDS ? 1 : 0;
+    e->tree_lds = TLDS;
     e->dyn_lds = L.total;
     e->waves = NW; e->groups = NG;
     hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
     return hipGetLastError();
 }
 
-template <int ENV, int HP, int NREG, bool TLDS, int NW, int NG>
+template <int ENV, int HP, int NREG, int TLDS, int NW, int NG>
 static hipError_t launch_t(azg_engine* e) {
     if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4) {
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
@@ -128,9 +128,14 @@ static hipError_t launch_t(azg_engine* e) {
 template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {
     const int ns = e->cfg.n_sims;
-    bool lds_ok = e->R <= 255 && e->Kp == 16 && 4 * ns + 4 < 65536;
+    // LDS trees: <= 16 children per node; 8-bit ids / 16-bit counts up to 255 records, 9-bit ids / 11-bit counts up to 511
+    int ts = TS_GLOBAL;
+    if (e->Kp == 16) {
+        if (e->R <= 255 && 4 * ns + 4 < 65536) ts = TS_LDS8;
+        else if (e->R <= 511 && 4 * ns + 4 < 2048) ts = TS_LDS9;
+    }
     const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
-    if (force && force[0] == '1') lds_ok = false;
+    if (force && force[0] == '1') ts = TS_GLOBAL;
     if constexpr (HP == 256 && NREG == 1) {
         const char* w = getenv("AZG_WAVES");
         const char* g = getenv("AZG_GROUPS");
@@ -140,18 +145,22 @@ static hipError_t launch(azg_engine* e) {
         bool want8 = two;
         if (w && w[0] == '8') want8 = true;
         if (w && w[0] == '4') want8 = false;
-        if (want8 && lds_ok && e->P.ncomp < 2) {
+        if (want8 && ts == TS_LDS8 && e->P.ncomp < 2) {
             hipError_t rc = hipErrorInvalidConfiguration;
-            if (two) rc = launch_t<ENV, HP, NREG, true, 8, 2>(e);
-            if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, true, 8, 1>(e);
+            if (two) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 2>(e);
+            if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 1>(e);
             if (rc != hipErrorInvalidConfiguration) return rc;
         }
     }
-    if (lds_ok) {
-        hipError_t rc = launch_t<ENV, HP, NREG, true, 4, 1>(e);
+    if (ts == TS_LDS8) {
+        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1>(e);
         if (rc != hipErrorInvalidConfiguration) return rc;
     }
-    return launch_t<ENV, HP, NREG, false, 4, 1>(e);
+    if (ts == TS_LDS9) {
+        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS9, 4, 1>(e);
+        if (rc != hipErrorInvalidConfiguration) return rc;
+    }
+    return launch_t<ENV, HP, NREG, TS_GLOBAL, 4, 1>(e);
 }
 
 template <int ENV>

@@ -30,6 +30,23 @@ struct __attribute__((aligned(16))) RecS {
     unsigned char cbase;     // continuous, n_child >= 2: the child list starts at pool[4 * cbase]
 };
 #define POOL_UNITS(R) ((7 * ((R) - 1) + 8) / 9 + 1)
+// The same record for trees of 256..511 records (9-bit ids, counts < 2048): everything but Q packed into one 64-bit word.
+// Its child-list pool holds 16-bit ids (units of 4 ids = 8 bytes).
+struct __attribute__((aligned(16))) RecM {
+    double Q;
+    unsigned long long edge_n : 11;
+    unsigned long long node_n : 11;
+    unsigned long long parent : 9;
+    unsigned long long first : 9;
+    unsigned long long cbase : 9;
+    unsigned long long n_child : 5;
+    unsigned long long flags : 2;
+};
+static_assert(sizeof(RecM) == 16, "RecM must be 16 bytes");
+// tree storage of a kernel variant: global memory (RecL), LDS with 8-bit ids (RecS), LDS with 9-bit ids (RecM)
+#define TS_GLOBAL 0
+#define TS_LDS8 1
+#define TS_LDS9 2
 struct __attribute__((aligned(8))) RecL {
     double Q;
     int edge_n;

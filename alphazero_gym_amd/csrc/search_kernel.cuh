@@ -18,19 +18,19 @@ struct LdsLayout {
     size_t per_tree;   // bytes per tree: R records of 16 B + child-list pool (continuous) or R priors (discrete)
     size_t total;
 };
-__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, bool tlds) {
+__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, int tlds) {
     LdsLayout L;
     L.act_off = ((size_t)tab_n * 8 + (size_t)(n_sims + 2) * 2 + 15) / 16 * 16;
     L.tree_off = L.act_off + (size_t)nbuf * NG * HP * 64;
-    L.per_tree = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * 4 : (size_t)R * 4);
+    L.per_tree = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * (tlds == TS_LDS9 ? 8 : 4) : (size_t)R * 4);   // 4 ids per pool unit
     L.per_tree = (L.per_tree + 15) / 16 * 16;
-    L.total = L.tree_off + (tlds ? L.per_tree * 16 * NG : 0);
+    L.total = L.tree_off + (tlds != TS_GLOBAL ? L.per_tree * 16 * NG : 0);
     return L;
 }
 // activation buffers a kernel variant needs: one when a single register-resident hidden layer reads what layer 0 wrote
 __host__ __device__ constexpr int act_buffers(int NREG) { return NREG == 1 ? 1 : 2; }
 
-template <int ENV, int HP, int NREG, bool TLDS, bool GMM, int NW, int NG>
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
 __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int TPW = 16 * NG;        // trees per workgroup
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
     double* edge_W = P.edge_W + tb;
     float* action = P.action + tb;
     TreeStore<TLDS> ts;
-    if constexpr (TLDS) {
+    if constexpr (TLDS != TS_GLOBAL) {
         // per tree: R records of 16 B, then (continuous) the child-list pool or (discrete) R priors
         char* base = (char*)s_dyn + L.tree_off + L.per_tree * tl;
         ts.hot = (Rec*)base;
-        ts.pool = (unsigned char*)(base + (size_t)P.R * 16);
+        ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
         ts.prior = (float*)(base + (size_t)P.R * 16);
     } else {
         ts.hot = (Rec*)(P.hot + tb);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
 #endif
     if (live) {
         if (sub == 0) P.n_rec[tree] = nrec;
-        if constexpr (TLDS) {
+        if constexpr (TLDS != TS_GLOBAL) {
             // publish the LDS-resident tree in the global format
             RecL* gh = P.hot + tb;
             for (int j = sub; j < nrec; j += 16) {

@@ -103,34 +103,37 @@ __device__ __forceinline__ int argmax2_payload(double u, int sub, int payload) {
 // storage of the hot part of one tree: LDS (RecS, 8-bit ids, pooled child lists) or global memory (RecL, 16-bit ids,
 // a [Kp]-wide child table per record).  child_at / child_append are the continuous-mode child list accessors; the
 // arguments of child_append are uniform over the tree's 16 lanes and only `writer` (lane 0) stores.
-template <bool TLDS> struct TreeStore;
-template <> struct TreeStore<true> {
-    typedef RecS Rec;
-    Rec* hot; unsigned char* pool; float* prior;
+template <int TLDS> struct TreeStore;
+// LDS-resident trees: RecS + byte pool (TS_LDS8) or RecM + 16-bit pool (TS_LDS9), same logic
+template <typename RecT, typename IdT> struct TreeStoreLds {
+    typedef RecT Rec;
+    typedef IdT PoolId;
+    Rec* hot; IdT* pool; float* prior;
     __device__ __forceinline__ int child_at(int, const Rec& hp, int i, int) const {
         return hp.n_child == 1 ? (int)hp.first : (int)pool[4 * (int)hp.cbase + i];
     }
     __device__ __forceinline__ void child_append(int p, const Rec& hp, int K, int id, int& ptop, bool writer, int) const {
         const int cb = hp.cbase;
         if (K == 0) {
-            if (writer) hot[p].first = (unsigned char)id;
+            if (writer) hot[p].first = (decltype(hp.first))id;
         } else if (K == 1 || K == 4 || K == 8) {
             const int nb = ptop;
             ptop += K == 1 ? 1 : K / 2;   // blocks of 4, 8, 16 ids
             if (writer) {
-                unsigned* pw = (unsigned*)pool;
-                if (K == 1) pool[4 * nb] = hp.first;
-                else for (int w = 0; w < K / 4; ++w) pw[nb + w] = pw[cb + w];
-                pool[4 * nb + K] = (unsigned char)id;
-                hot[p].cbase = (unsigned char)nb;
+                if (K == 1) pool[4 * nb] = (IdT)hp.first;
+                else for (int w = 0; w < K; ++w) pool[4 * nb + w] = pool[4 * cb + w];
+                pool[4 * nb + K] = (IdT)id;
+                hot[p].cbase = (decltype(hp.cbase))nb;
             }
         } else {
-            if (writer) pool[4 * cb + K] = (unsigned char)id;
+            if (writer) pool[4 * cb + K] = (IdT)id;
         }
-        if (writer) hot[p].n_child = (unsigned char)(K + 1);
+        if (writer) hot[p].n_child = (decltype(hp.n_child))(K + 1);
     }
 };
-template <> struct TreeStore<false> {
+template <> struct TreeStore<TS_LDS8> : TreeStoreLds<RecS, unsigned char> {};
+template <> struct TreeStore<TS_LDS9> : TreeStoreLds<RecM, unsigned short> {};
+template <> struct TreeStore<TS_GLOBAL> {
     typedef RecL Rec;
     Rec* hot; unsigned short* child; float* prior;
     __device__ __forceinline__ int child_at(int p, const Rec&, int i, int Kp) const { return (int)child[p * Kp + i]; }
@@ -146,12 +149,13 @@ __device__ __forceinline__ Rec make_edge(double Q, int parent) {
     return h;
 }
 __device__ __forceinline__ void clear_pad(RecS& h) { h.cbase = 0; }
+__device__ __forceinline__ void clear_pad(RecM& h) { h.cbase = 0; }
 __device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
 
 // MCTS.backprop (mcts.py:260-267), generic part: walks parent links from record j to the root, 16 levels at a time
 // (lane d = d-th record), fetches rewards / W in parallel, chains the discounted return serially (its rounding order
 // is part of the contract), then every lane updates its own record.
-template <bool CONT, bool TLDS>
+template <bool CONT, int TLDS>
 __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int j, float V, int sub,
                                             float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv) {
     typedef typename TreeStore<TLDS>::Rec Rec;
@@ -206,7 +210,7 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 
 // Backup of a trace whose path the descent left in the lanes: slot (depth & 15) holds the record id, its reward and W
 // (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
-template <bool CONT, bool TLDS>
+template <bool CONT, int TLDS>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
                                             double gamma, int D, int my_depth, int pid, double pr, double pW) {
     typedef typename TreeStore<TLDS>::Rec Rec;

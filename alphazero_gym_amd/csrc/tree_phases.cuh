@@ -22,7 +22,7 @@ struct TreeState {
 
 // initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
 // workgroup (TPW trees per workgroup, tl = the tree's index in it)
-template <int ENV, bool TLDS, int TPW = 16>
+template <int ENV, int TLDS, int TPW = 16>
 __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                                float* action, int tree, bool live, int sub, int tl, unsigned gtree, float* obsT) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
@@ -58,7 +58,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 // Phase A: give the evaluated leaf its value / policy (evaluation, add_value_estimate: mcts.py:385-416, 602-623; the root's first
 // action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase
 // for the tree's group of 16 (PSTR entries per chunk), tl = the tree's column in that group.
-template <int ENV, bool TLDS, bool GMM, int NCH, int PSTR = 64>
+template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
                                              const float* bhead) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 
 // Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
 // step the environment and create the node (expansion: mcts.py:216-238); leaves the new leaf's observation in obsT.
-template <int ENV, bool TLDS, bool GMM, int TPW = 16, typename PW = int>
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM) {
