@@ -253,3 +253,24 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=sidx)
     b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=sidx)
     _assert_same(a, b)
+
+
+def test_headline_search_stays_within_its_time_budget(native):
+    """Guard against performance regressions of the one-launch search (BASELINE config C).  Measured 1.70 ms per search on an
+    MI355X (4.8e8 sims/s); the budget is loose enough for box-to-box variance and a cold first launch."""
+    kw = dict(env_id=2, mode=1, n_trees=4096, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+    e = native.HipEngine(**kw)
+    e.set_weights(_capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2))
+    e.upload_roots(e.synthetic_roots())
+    for _ in range(3):
+        e.search_resident()
+    e.sync()
+    ms = min(_timed_ms(e) for _ in range(5))
+    e.close()
+    assert ms < 2.3, f"search kernel took {ms:.3f} ms (budget 2.3 ms = 3.6e8 sims/s)"
+
+
+def _timed_ms(e):
+    e.search_resident()
+    e.sync()
+    return e.last_search_ms()
