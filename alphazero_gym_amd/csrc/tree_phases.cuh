@@ -172,8 +172,11 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             const bool valid = sub < K;
             int c = 0;
             double U = 0.0;
-            if (valid) {
-                c = CONT ? ts.child_at(p, hp, sub, P.Kp) : (int)hp.first + sub;
+            {
+                // no branch around the loads: lanes beyond the last child score record 0 and are masked out of the arg-max
+                const int si = valid ? sub : 0;
+                c = CONT ? ts.child_at(p, hp, si, P.Kp) : (int)hp.first + si;
+                if (!valid) c = 0;
                 Rec h = ts.hot[c];
                 double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
                 if (CONT) {
