@@ -235,7 +235,9 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             st.my_depth = st.path_D; st.pid = chosen;
             st.pr = cold[chosen].r; st.pW = edge_W[chosen];
         }
-        if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
+        if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
+            if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
+        }
         if (CONT) cp = cold[p];   // Pendulum: a trace is 2-3 levels deep and the prefetch hides the one exposed global round trip;
                                   // CartPole: 8-9 levels, issuing it at every level costs more than waiting once (measured)
         STAMP(tl4);
