@@ -143,7 +143,7 @@ def main():
             "config": {"workload": f"Pendulum-v1 A0C, {B} trees/GPU x {N_SIMS} sims, 2x256 ELU policy/value MLP, c_uct=0.05 c_pw=1 kappa=0.5",
                        "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": f"{world} independent shards (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": profiled_traffic(), "kernel": "search_kernel<2, 256, 1, true, false, 4, 1> (ENV=Pendulum, HP=256, NREG=1, TLDS, no GMM, 4 waves, 1 tree group)", "kernel_ms": kms,
+                         "traffic": profiled_traffic(), "kernel": "search_kernel<2, 256, 1, 1, false, 4, 1> (ENV=Pendulum, HP=256, NREG=1, trees in LDS with 8-bit ids, no GMM, 4 waves, 1 tree group)", "kernel_ms": kms,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/)"},
