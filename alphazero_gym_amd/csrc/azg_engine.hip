@@ -22,45 +22,13 @@
 #include <string>
 #include <vector>
 
-#include "records.h"
+#include "engine_host.h"
 #include "env.cuh"
 #include "mlp.cuh"
 #include "tree.cuh"
-#include "search_kernel.cuh"
 #include "aux_kernels.cuh"
-#include "lockstep.cuh"
 
 // ------------------------------------------------------------------------------------------------ host side
-
-struct azg_engine {
-    azg_config cfg;
-    int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
-    int mlp_ready, HP, n_hidden, n_out, act, nreg;
-    int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
-    int waves, groups, n_cus; // waves / 16-tree groups per workgroup of the last launch; compute units of the device
-    size_t dyn_lds;          // dynamic LDS bytes per workgroup
-    float ls_min, ls_max;
-    hipStream_t stream;
-    hipEvent_t ev0, ev1;
-    KParams P;
-    std::vector<void*> dev_allocs;
-    std::vector<void*> weight_allocs;
-    // results staging
-    float* d_actions; int* d_counts; double* d_Q; double* d_vt; int* d_nch; int* d_child_n; double* d_child_state;
-    float* d_rootV; float* d_rootdist;
-    double* d_roots; int* d_carry;
-    uint32_t search_idx;
-    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
-    uint32_t sp_step_idx;
-    int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
-    std::vector<void*> sp_allocs;
-    LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
-    std::vector<void*> ls_allocs;
-    int ls_hp;
-    int searched, results_valid;
-    float last_ms;
-    std::string err;
-};
 
 static std::string g_create_err;
 
@@ -85,108 +53,6 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
     return AZG_OK;
 }
 
-// One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
-// Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
-template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
-static hipError_t launch_g(azg_engine* e) {
-    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
-    static int static_lds = -1;
-    if (static_lds < 0) {
-        hipFuncAttributes fa;
-        hipError_t rc = hipFuncGetAttributes(&fa, (const void*)kern);
-        if (rc != hipSuccess) return rc;
-        static_lds = (int)fa.sharedSizeBytes;
-    }
-    const LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, ENV != AZG_ENV_CARTPOLE, TLDS);
-    if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
-    if (L.total > 48 * 1024) {
-        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
-        if (rc != hipSuccess) return rc;
-    }
-    const int tpw = 16 * NG;
-    dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
-    e->tree_lds = TLDS;
-    e->dyn_lds = L.total;
-    e->waves = NW; e->groups = NG;
-    hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
-    return hipGetLastError();
-}
-
-template <int ENV, int HP, int NREG, int TLDS, int NW, int NG>
-static hipError_t launch_t(azg_engine* e) {
-    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4) {
-        if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
-    }
-    return launch_g<ENV, HP, NREG, TLDS, false, NW, NG>(e);
-}
-
-// Variant choice.  Trees live in LDS when they fit (8-bit record ids, 16-bit counts, <= 16 children per node, the CU's 160 KB).
-// While every 16-tree group can have a CU of its own, the 4-wave / 16-tree workgroup is the fastest shape (measured: the
-// 8-wave / 16-tree shape ties with it, the VALU work per SIMD being the same).  Once a batch has more groups than the device
-// has CUs, 2x256 Normal / 2-action networks run as 8-wave / 32-tree workgroups: two waves per SIMD, so one wave's tree walk
-// and activation math overlaps the other's MFMAs (1.27x at 8192 trees).  AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
-template <int ENV, int HP, int NREG>
-static hipError_t launch(azg_engine* e) {
-    const int ns = e->cfg.n_sims;
-    // LDS trees: <= 16 children per node; 8-bit ids / 16-bit counts up to 255 records, 9-bit ids / 11-bit counts up to 511
-    int ts = TS_GLOBAL;
-    if (e->Kp == 16) {
-        if (e->R <= 255 && 4 * ns + 4 < 65536) ts = TS_LDS8;
-        else if (e->R <= 511 && 4 * ns + 4 < 2048) ts = TS_LDS9;
-    }
-    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
-    if (force && force[0] == '1') ts = TS_GLOBAL;
-    if constexpr (HP == 256 && NREG == 1) {
-        const char* w = getenv("AZG_WAVES");
-        const char* g = getenv("AZG_GROUPS");
-        bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
-        if (g && g[0] == '2') two = true;
-        if (g && g[0] == '1') two = false;
-        bool want8 = two;
-        if (w && w[0] == '8') want8 = true;
-        if (w && w[0] == '4') want8 = false;
-        if (want8 && ts == TS_LDS8 && e->P.ncomp < 2) {
-            hipError_t rc = hipErrorInvalidConfiguration;
-            if (two) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 2>(e);
-            if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 1>(e);
-            if (rc != hipErrorInvalidConfiguration) return rc;
-        }
-    }
-    if (ts == TS_LDS8) {
-        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1>(e);
-        if (rc != hipErrorInvalidConfiguration) return rc;
-    }
-    if (ts == TS_LDS9) {
-        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS9, 4, 1>(e);
-        if (rc != hipErrorInvalidConfiguration) return rc;
-    }
-    return launch_t<ENV, HP, NREG, TS_GLOBAL, 4, 1>(e);
-}
-
-template <int ENV>
-static hipError_t dispatch(azg_engine* e) {
-    const int HP = e->HP, NR = e->nreg;
-    if (HP == 64) {
-        if (NR == 1) return launch<ENV, 64, 1>(e);
-        if (NR == 2) return launch<ENV, 64, 2>(e);
-        if (NR == 3) return launch<ENV, 64, 3>(e);
-        return launch<ENV, 64, 0>(e);
-    }
-    if (HP == 128) {
-        if (NR == 1) return launch<ENV, 128, 1>(e);
-        if (NR == 2) return launch<ENV, 128, 2>(e);
-        if (NR == 3) return launch<ENV, 128, 3>(e);
-        return launch<ENV, 128, 0>(e);
-    }
-    if (HP == 256) {
-        if (NR == 1) return launch<ENV, 256, 1>(e);
-        return launch<ENV, 256, 0>(e);
-    }
-    if (HP == 512) return launch<ENV, 512, 0>(e);
-    if (HP == 1024) return launch<ENV, 1024, 0>(e);
-    return hipErrorInvalidValue;
-}
-
 // ---- lock-step path (wide networks): a few grid-wide launches per simulation step
 static int ls_prepare(azg_engine* e) {
     if (e->ls_hp == e->HP) return AZG_OK;
@@ -205,63 +71,6 @@ static int ls_prepare(azg_engine* e) {
     if (hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
     e->ls_hp = e->HP;
     return AZG_OK;
-}
-
-template <int ENV, int HP, bool GMM>
-static hipError_t ls_run(azg_engine* e) {
-    constexpr int NS = HP / 256, NCH = HP / 64;
-    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG;
-    const size_t tab_bytes = ((size_t)e->tab_n * 8 + (size_t)(e->cfg.n_sims + 2) * 4 + 15) / 16 * 16;
-    const size_t act_bytes = (size_t)HP * 64;
-    auto tk = ls_tree_kernel<ENV, GMM, NCH>;
-    auto hk = ls_hidden_kernel<HP, false>;
-    auto hl = ls_hidden_kernel<HP, true>;
-    if (act_bytes > 48 * 1024) {
-        hipError_t rc = hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_bytes);
-        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)hl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)act_bytes);
-        if (rc != hipSuccess) return rc;
-    }
-    // hidden layers: the LDS-tiled kernel; AZG_LS_TILED=0 keeps the 16-tree x 256-unit weight-streaming kernel (diagnostics)
-    // (32 trees x 64 units per workgroup: two workgroups per CU at 1024 trees x 1024 units)
-    auto tkh = ls_hidden_tiled_kernel<HP, false, 2, 4>;
-    auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
-    const int TQ = (G + 1) / 2, NU = HP / 64;
-    const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
-    const char* tenv = getenv("AZG_LS_TILED");
-    const bool tiled = !(tenv && tenv[0] == '0');
-    if (tiled) {
-        hipError_t rc = hipFuncSetAttribute((const void*)tkh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
-        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
-        if (rc != hipSuccess) return rc;
-    }
-    hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, -2);
-    for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
-        hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(G * NS), dim3(256), 0, e->stream, e->P, e->ls);
-        for (int l = 1; l < e->n_hidden; ++l) {
-            const bool last = l == e->n_hidden - 1;
-            if (tiled) {
-                if (last) hipLaunchKernelGGL(tkl, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
-                else hipLaunchKernelGGL(tkh, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
-            } else if (last) {
-                hipLaunchKernelGGL(hl, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
-            } else {
-                hipLaunchKernelGGL(hk, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
-            }
-        }
-        hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, sim);
-    }
-    return hipGetLastError();
-}
-
-template <int ENV>
-static hipError_t ls_dispatch(azg_engine* e) {
-    const bool gmm = ENV != AZG_ENV_CARTPOLE && e->P.ncomp >= 2;
-    if (e->HP == 512) {
-        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 512, true>(e); }
-        return ls_run<ENV, 512, false>(e);
-    }
-    if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 1024, true>(e); }
-    return ls_run<ENV, 1024, false>(e);
 }
 
 static bool use_lockstep(const azg_engine* e) {
@@ -584,8 +393,10 @@ int azg_search_resident(azg_engine* e) {
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     hipError_t rc;
-    if (lockstep) rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? ls_dispatch<AZG_ENV_CARTPOLE>(e) : ls_dispatch<AZG_ENV_PENDULUM_V1>(e);
-    else rc = e->cfg.env_id == AZG_ENV_CARTPOLE ? dispatch<AZG_ENV_CARTPOLE>(e) : dispatch<AZG_ENV_PENDULUM_V1>(e);
+    const bool cartpole = e->cfg.env_id == AZG_ENV_CARTPOLE;
+    if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : azg_ls_dispatch_pendulum(e);
+    else if (cartpole) rc = azg_dispatch_cartpole(e);
+    else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;

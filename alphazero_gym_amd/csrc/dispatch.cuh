@@ -1,0 +1,120 @@
+// dispatch.cuh -- host-side choice and launch of the persistent search kernel variants (included by the dispatch_*.hip
+// translation units, each of which instantiates one family of them).
+#pragma once
+#include <cstdlib>
+
+#include "engine_host.h"
+#include "env.cuh"
+#include "mlp.cuh"
+#include "tree.cuh"
+#include "search_kernel.cuh"
+
+// One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
+// Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
+static hipError_t launch_g(azg_engine* e) {
+    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
+    static int static_lds = -1;
+    if (static_lds < 0) {
+        hipFuncAttributes fa;
+        hipError_t rc = hipFuncGetAttributes(&fa, (const void*)kern);
+        if (rc != hipSuccess) return rc;
+        static_lds = (int)fa.sharedSizeBytes;
+    }
+    const LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, ENV != AZG_ENV_CARTPOLE, TLDS);
+    if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
+    if (L.total > 48 * 1024) {
+        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+        if (rc != hipSuccess) return rc;
+    }
+    const int tpw = 16 * NG;
+    dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
+    e->tree_lds = TLDS;
+    e->dyn_lds = L.total;
+    e->waves = NW; e->groups = NG;
+    hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
+    return hipGetLastError();
+}
+
+template <int ENV, int HP, int NREG, int TLDS, int NW, int NG>
+static hipError_t launch_t(azg_engine* e) {
+    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4) {
+        if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
+    }
+    return launch_g<ENV, HP, NREG, TLDS, false, NW, NG>(e);
+}
+
+// Variant choice.  Trees live in LDS when they fit (8-bit record ids, 16-bit counts, <= 16 children per node, the CU's 160 KB).
+// While every 16-tree group can have a CU of its own, the 4-wave / 16-tree workgroup is the fastest shape (measured: the
+// 8-wave / 16-tree shape ties with it, the VALU work per SIMD being the same).  Once a batch has more groups than the device
+// has CUs, 2x256 Normal / 2-action networks run as 8-wave / 32-tree workgroups: two waves per SIMD, so one wave's tree walk
+// and activation math overlaps the other's MFMAs (1.27x at 8192 trees).  AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
+template <int ENV, int HP, int NREG>
+static hipError_t launch(azg_engine* e) {
+    const int ns = e->cfg.n_sims;
+    // LDS trees: <= 16 children per node; 8-bit ids / 16-bit counts up to 255 records, 9-bit ids / 11-bit counts up to 511
+    int ts = TS_GLOBAL;
+    if (e->Kp == 16) {
+        if (e->R <= 255 && 4 * ns + 4 < 65536) ts = TS_LDS8;
+        else if (e->R <= 511 && 4 * ns + 4 < 2048) ts = TS_LDS9;
+    }
+    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
+    if (force && force[0] == '1') ts = TS_GLOBAL;
+    if constexpr (HP == 256 && NREG == 1) {
+        const char* w = getenv("AZG_WAVES");
+        const char* g = getenv("AZG_GROUPS");
+        bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
+        if (g && g[0] == '2') two = true;
+        if (g && g[0] == '1') two = false;
+        bool want8 = two;
+        if (w && w[0] == '8') want8 = true;
+        if (w && w[0] == '4') want8 = false;
+        if (want8 && ts == TS_LDS8 && e->P.ncomp < 2) {
+            hipError_t rc = hipErrorInvalidConfiguration;
+            if (two) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 2>(e);
+            if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 1>(e);
+            if (rc != hipErrorInvalidConfiguration) return rc;
+        }
+    }
+    if (ts == TS_LDS8) {
+        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1>(e);
+        if (rc != hipErrorInvalidConfiguration) return rc;
+    }
+    if (ts == TS_LDS9) {
+        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS9, 4, 1>(e);
+        if (rc != hipErrorInvalidConfiguration) return rc;
+    }
+    return launch_t<ENV, HP, NREG, TS_GLOBAL, 4, 1>(e);
+}
+
+// hidden widths (padded) up to 128
+template <int ENV>
+static hipError_t dispatch_small(azg_engine* e) {
+    const int HP = e->HP, NR = e->nreg;
+    if (HP == 64) {
+        if (NR == 1) return launch<ENV, 64, 1>(e);
+        if (NR == 2) return launch<ENV, 64, 2>(e);
+        if (NR == 3) return launch<ENV, 64, 3>(e);
+        return launch<ENV, 64, 0>(e);
+    }
+    if (HP == 128) {
+        if (NR == 1) return launch<ENV, 128, 1>(e);
+        if (NR == 2) return launch<ENV, 128, 2>(e);
+        if (NR == 3) return launch<ENV, 128, 3>(e);
+        return launch<ENV, 128, 0>(e);
+    }
+    return hipErrorInvalidValue;
+}
+// 256 and wider
+template <int ENV>
+static hipError_t dispatch_large(azg_engine* e) {
+    const int HP = e->HP, NR = e->nreg;
+    if (HP == 256) {
+        if (NR == 1) return launch<ENV, 256, 1>(e);
+        return launch<ENV, 256, 0>(e);
+    }
+    if (HP == 512) return launch<ENV, 512, 0>(e);
+    if (HP == 1024) return launch<ENV, 1024, 0>(e);
+    return hipErrorInvalidValue;
+}
+

@@ -1,0 +1,47 @@
+// engine_host.h -- the engine object behind the C ABI and the entry points of the kernel translation units.
+// The persistent search kernels are compiled in several translation units (dispatch_*.hip: one family of template
+// instantiations each) so that the library builds in parallel; azg_engine.hip holds the C ABI and the small kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "records.h"
+
+struct azg_engine {
+    azg_config cfg;
+    int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
+    int mlp_ready, HP, n_hidden, n_out, act, nreg;
+    int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
+    int waves, groups, n_cus; // waves / 16-tree groups per workgroup of the last launch; compute units of the device
+    size_t dyn_lds;          // dynamic LDS bytes per workgroup
+    float ls_min, ls_max;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    KParams P;
+    std::vector<void*> dev_allocs;
+    std::vector<void*> weight_allocs;
+    // results staging
+    float* d_actions; int* d_counts; double* d_Q; double* d_vt; int* d_nch; int* d_child_n; double* d_child_state;
+    float* d_rootV; float* d_rootdist;
+    double* d_roots; int* d_carry;
+    uint32_t search_idx;
+    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
+    uint32_t sp_step_idx;
+    int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
+    std::vector<void*> sp_allocs;
+    LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
+    std::vector<void*> ls_allocs;
+    int ls_hp;
+    int searched, results_valid;
+    float last_ms;
+    std::string err;
+};
+
+// one search of all trees on e->stream with the kernel variant that fits (dispatch.cuh); hipErrorInvalidValue: no such variant
+hipError_t azg_dispatch_cartpole(azg_engine* e);
+hipError_t azg_dispatch_pendulum_small(azg_engine* e);   // hidden width (padded) <= 128
+hipError_t azg_dispatch_pendulum_large(azg_engine* e);   // 256 and wider
+hipError_t azg_ls_dispatch_cartpole(azg_engine* e);      // lock-step path (lockstep.cuh), buffers prepared by the caller
+hipError_t azg_ls_dispatch_pendulum(azg_engine* e);

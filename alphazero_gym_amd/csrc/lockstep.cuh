@@ -15,17 +15,6 @@
 #include "tree.cuh"
 #include "tree_phases.cuh"
 
-struct LsLane { int my_depth, pid; double pr, pW; float eps_c; float pad; };
-struct LsTree { int nrec; unsigned eps_draws; int leaf, need_eval, path_D, kbase; };
-
-struct LockStep {
-    float* obsT;        // [G][4][16]
-    f32x4* act[2];      // [G][HP/16][64]   ping-pong activations (D-register layout)
-    f32x4* parts;       // [G][HP/64][64]   partial head sums, one per 64-unit chunk
-    LsTree* tree;       // [B]
-    LsLane* lane;       // [B][16]
-};
-
 template <int ENV, bool GMM, int NCH>
 __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int sim) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);

@@ -105,6 +105,19 @@ struct KParams {
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };
 
+// ---- state of the lock-step path (lockstep.cuh) between its launches
+struct LsLane { int my_depth, pid; double pr, pW; float eps_c; float pad; };
+struct LsTree { int nrec; unsigned eps_draws; int leaf, need_eval, path_D, kbase; };
+
+struct LockStep {
+    float* obsT;        // [G][4][16]
+    f32x4* act[2];      // [G][HP/16][64]   ping-pong activations (D-register layout)
+    f32x4* parts;       // [G][HP/64][64]   partial head sums, one per 64-unit chunk
+    LsTree* tree;       // [B]
+    LsLane* lane;       // [B][16]
+};
+
+
 #ifdef AZG_STAMPS
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)

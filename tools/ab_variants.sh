@@ -1,8 +1,9 @@
 #!/bin/bash
 # A/B timing of engine builds on ONE GPU box (box-to-box variance is 1-2 %, same-box repeatability about 0.1 %).
-# Build each variant in-tree next to the product library, e.g.
-#   hipcc $(HIPFLAGS) -DAZG_X_SOMETHING -shared -o alphazero_gym_amd/csrc/libazgym_hip_x_NAME.so alphazero_gym_amd/csrc/azg_engine.hip
-# then:  gpurun -- 'bash tools/ab_variants.sh base NAME ...'
+# Build each variant in-tree next to the product library:
+#   make -j8 -C alphazero_gym_amd/csrc variant NAME=foo DEFS=-DAZG_X_FOO      ->  libazgym_hip_x_foo.so
+# (or copy the current libazgym_hip.so to libazgym_hip_x_prev.so before changing the sources), then:
+#   gpurun -- 'bash tools/ab_variants.sh base foo ...'
 # Per variant: the GPU test suite's verdict, two headline bench runs (ms per search), configs B and E.
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 for v in "$@"; do
