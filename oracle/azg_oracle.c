@@ -867,6 +867,12 @@ void azo_eps_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, 
 
 float azo_sample_action(float mu, float sigma, float eps, float bound) { return bound * azg_tanhf(mu + sigma * eps); }
 
+/* the uniform that picks the mixture component of widening draw `draw` (third word of the draw's Philox block) */
+float azo_gmm_u(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw) {
+    azg_u32x4 b = azg_draw(seed, tree, search, draw, AZG_STREAM_PW);
+    return azg_u01(b.v[2]);
+}
+
 /* batched evaluator for tests: obs [n][S_obs] -> value [n], dist [n][n_dist], raw [n][1+n_dist] */
 int azo_mlp_eval(azg_engine* e, const float* obs, size_t n, float* value, float* dist, float* raw) {
     if (!e || !e->mlp.ready) return AZG_E_STATE;

@@ -444,6 +444,49 @@ def run_t3():
         s, actions, counts, Q, V = m.return_results("max_visit")
         counts_l.append(np.asarray(counts, np.int32)); Q_l.append(np.asarray(Q, np.float64)); V_l.append(float(V))
     out["d_roots"] = roots; out["d_counts"] = np.stack(counts_l); out["d_Q"] = np.stack(Q_l); out["d_v_target"] = np.array(V_l)
+    # continuous, the reference's default head: 2-component Gaussian mixture (DiagonalGMMPolicy).  MixtureSameFamily.sample draws
+    # the component with torch.multinomial and every component's Normal with one torch.normal call: both patched to the
+    # engine's draws of the widening record (uniform = third Philox word, N(0,1) = the record's noise)
+    hidden = [128, 128, 128]
+    blob = O.make_weights(35, 3, hidden, 6)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                      num_components=2, action_bound=2.0)
+    set_policy_weights(pol, blob, 3, hidden, 6)
+    roots = np.array([[0.75, -0.5], [-2.9, 0.9], [3.0, 0.1], [1.2, 0.3]])
+    counts_l, Q_l, act_l, V_l, margin = [], [], [], [], []
+    orig_multinomial = torch.multinomial
+    for ti, root in enumerate(roots):
+        state = {"n": 0}
+
+        def fake_multinomial(probs, num_samples, replacement=False, **k):
+            state["n"] += 1                                  # one widening record per sample_action call
+            u = np.float32(O.gmm_u(seed, ti, 0, state["n"]))
+            cum = np.cumsum(probs.detach().numpy().astype(np.float32), axis=-1, dtype=np.float32)
+            margin.append(float(np.min(np.abs(cum[..., :-1] - u))))
+            idx = (u >= cum[..., :-1]).sum(-1)
+            return torch.as_tensor(idx, dtype=torch.long).reshape(probs.shape[:-1] + (1,))
+
+        def fake_normal(mean, std, *a, **k):
+            eps = O.normal(seed, ti, 0, state["n"])
+            return mean + std * np.float32(eps)
+
+        torch.multinomial = fake_multinomial
+        torch.normal = fake_normal
+        COUNTER["n"] = 0
+        env = PendulumEnv(state=root, version=1)
+        m = RM.MCTSContinuous(model=pol, n_rollouts=60, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0, V_target_policy="off_policy",
+                              device="cpu", root_state=env._get_obs())
+        m.search(env)
+        s, actions, counts, Q, V = m.return_results("max_visit")
+        K = 8
+        assert len(counts) == K, len(counts)
+        counts_l.append(np.asarray(counts, np.int32)); Q_l.append(np.array([np.asarray(q).reshape(-1)[0] for q in Q]))
+        act_l.append(np.asarray(actions, np.float32).reshape(-1)); V_l.append(float(np.asarray(V).reshape(-1)[0]))
+    torch.normal = orig_normal
+    torch.multinomial = orig_multinomial
+    assert min(margin) > 1e-4, min(margin)   # no component pick sits on a boundary of the cumulative mixture weights
+    out["g_roots"] = roots; out["g_counts"] = np.stack(counts_l); out["g_Q"] = np.stack(Q_l); out["g_actions"] = np.stack(act_l)
+    out["g_v_target"] = np.array(V_l)
     return out
 
 

@@ -44,6 +44,8 @@ def lib():
         _lib.azo_eps_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         _lib.azo_eps_draw.restype = None
         _lib.azo_sample_action.argtypes = [C.c_float] * 4
+        _lib.azo_gmm_u.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        _lib.azo_gmm_u.restype = C.c_float
         _lib.azo_sample_action.restype = C.c_float
         _lib.azo_math_eval.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
         _lib.azo_mlp_eval.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -76,6 +78,10 @@ class OracleEngine(_capi.Engine):
 
 def normal(seed, tree, search, draw):
     return float(lib().azo_normal(seed, tree, search, draw))
+
+
+def gmm_u(seed, tree, search, draw):
+    return float(lib().azo_gmm_u(seed, tree, search, draw))
 
 
 def eps_draw(seed, tree, search, draw):

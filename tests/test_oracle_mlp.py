@@ -3,6 +3,7 @@ and the oracle end to end against the reference with its real torch policy (tier
 import os
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
 import parity_util as P
@@ -84,3 +85,33 @@ def test_end_to_end_against_reference_with_torch_policy():
     for i, m in enumerate(match):
         if m:
             np.testing.assert_allclose(r["Q"][i], z["d_Q"][i], atol=TOL, rtol=TOL)
+
+
+def _gmm_end_to_end(engine_cls):
+    """T3, mixture head: the reference's MCTSContinuous with its own DiagonalGMMPolicy (2 components, 3x128 ELU: the default of
+    config/policy/ContinuousPolicy.yaml), component pick and Normal noise patched to the engine's draws."""
+    z = np.load(os.path.join(P.GOLDEN, "t3_end_to_end.npz"))
+    e = engine_cls(env_id=2, mode=1, n_trees=len(z["g_roots"]), n_sims=60, c_uct=0.05, gamma=1.0, c_pw=1, kappa=0.5, seed=34)
+    e.set_weights(_capi.make_desc(3, [128, 128, 128], 6, "elu", num_components=2), O.make_weights(35, 3, [128, 128, 128], 6))
+    e.search(z["g_roots"])
+    r = e.results()
+    e.close()
+    K = z["g_counts"].shape[1]
+    match = [np.array_equal(r["counts"][i][:K], z["g_counts"][i]) for i in range(len(z["g_roots"]))]
+    assert np.mean(match) >= 0.75, match
+    for i, m in enumerate(match):
+        if m:
+            np.testing.assert_allclose(r["Q"][i][:K], z["g_Q"][i], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(r["actions"][i][:K], z["g_actions"][i], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(r["v_target"][i], z["g_v_target"][i], atol=TOL, rtol=TOL)
+
+
+def test_end_to_end_against_reference_with_torch_mixture_policy():
+    _gmm_end_to_end(O.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_hip_end_to_end_against_reference_with_torch_mixture_policy():
+    from alphazero_gym_amd import _native
+    _native.lib()
+    _gmm_end_to_end(_native.HipEngine)
