@@ -593,6 +593,30 @@ def run_t5():
     return out
 
 
+def run_t6():
+    """The reference's ReplayBuffer (buffers.py:40-127) driven through wrap-around and two epochs of minibatches under a
+    fixed numpy seed: slot contents after every store and the sample ids of every batch."""
+    from alphazero.agent.buffers import ReplayBuffer
+    out = {}
+    buf = ReplayBuffer(max_size=7, batch_size=3)
+    slots = []
+    for i in range(17):
+        buf.store((np.full(3, i, np.float32), np.full(2, i, np.float32), np.full(2, i, np.float32), np.full(2, i, np.float32), np.float64(i)))
+        row = [int(e[4]) for e in buf.experience] + [-1] * (7 - len(buf.experience))
+        slots.append(row + [buf.insert_index, buf.size])
+    out["slots"] = np.array(slots)
+    np.random.seed(123)
+    buf.reshuffle()
+    batches = []
+    for epoch in range(2):
+        for b in buf:
+            ids = np.asarray(b[4]).reshape(-1).astype(np.int64)
+            batches.append(np.concatenate([[epoch, len(ids)], ids, [-1] * (8 - len(ids))]))
+            assert tuple(np.asarray(b[0]).shape) == (len(ids), 3)
+    out["batches"] = np.array(batches)
+    return out
+
+
 def main():
     for name, case in T1_CASES.items():
         TIES["n"] = 0
@@ -613,6 +637,9 @@ def main():
     t5 = run_t5()
     np.savez_compressed(os.path.join(HERE, "t5_training.npz"), **t5)
     print("t5", t5["c_a0c"], t5["c_a0c_tuned"], t5["d_az"])
+    t6 = run_t6()
+    np.savez_compressed(os.path.join(HERE, "t6_buffer.npz"), **t6)
+    print("t6", t6["slots"][-1].tolist(), t6["batches"].tolist())
     print("t3 ties", TIES["n"], "c_counts[0]", t3["c_counts"][0].tolist(), "d_counts", t3["d_counts"].tolist())
 
 

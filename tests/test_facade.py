@@ -233,3 +233,24 @@ def test_gmm_policy_runs_through_the_facade(backend):
     np.testing.assert_allclose(dist[:, 4:], np.cumsum(torch.softmax(log_coeff, -1).numpy(), 1), atol=1e-5, rtol=1e-5)
     for (s, a, c, q, v) in rows:
         assert c.sum() == 64 and len(a) == 8 and (np.abs(a) <= 2.0).all()
+
+
+def test_replay_buffer_matches_the_reference_slot_for_slot():
+    """T6 golden (tests/golden/gen_golden.py run_t6): the reference's ReplayBuffer through wrap-around and two epochs of
+    minibatches under a fixed numpy seed."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t6_buffer.npz"))
+    buf = ReplayBuffer(max_size=7, batch_size=3)
+    slots = []
+    for i in range(17):
+        buf.store((np.full(3, i, np.float32), np.full(2, i, np.float32), np.full(2, i, np.float32), np.full(2, i, np.float32), np.float64(i)))
+        row = [int(e[4]) for e in buf.experience] + [-1] * (7 - len(buf.experience))
+        slots.append(row + [buf.insert_index, buf.size])
+    np.testing.assert_array_equal(np.array(slots), z["slots"])
+    np.random.seed(123)
+    buf.reshuffle()
+    batches = []
+    for epoch in range(2):
+        for b in buf:
+            ids = np.asarray(b[4]).reshape(-1).astype(np.int64)
+            batches.append(np.concatenate([[epoch, len(ids)], ids, [-1] * (8 - len(ids))]))
+    np.testing.assert_array_equal(np.array(batches), z["batches"])
