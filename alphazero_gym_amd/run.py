@@ -186,7 +186,9 @@ class BatchedSelfPlay:
 
 class DeviceSelfPlay:
     """The same loop with everything but the optimiser on the GPU (azg_selfplay_* in include/azgym.h): games, final action
-    rule, env step, episode resets and the replay ring live on the device; the host only downloads rows to train on."""
+    rule, env step, episode resets and the replay ring live on the device; the host only downloads rows to train on.
+    The discrete final action is sampled with temperature 1.0 (the reference's default, config/agent/DiscreteAgent.yaml:11) or
+    taken greedily (``deterministic``); other temperatures: BatchedSelfPlay."""
 
     def __init__(self, policy, *, game: str, n_games: int, n_rollouts: int, c_uct: float, gamma: float = 1.0, epsilon: float = 0.0,
                  c_pw: float = 1.0, kappa: float = 0.5, V_target_policy: str = "off_policy", max_episode_length: int = 200,
