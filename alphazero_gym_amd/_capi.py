@@ -80,7 +80,7 @@ SYMBOLS = [
     "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_search_index", "search",
     "results", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
     "synthetic_roots", "last_search_ms", "upload_roots", "search_resident", "sync",
-    "selfplay_begin", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats",
+    "selfplay_begin", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats", "mlp_eval",
 ]
 
 
@@ -117,6 +117,7 @@ def bind(lib, prefix):
     f["selfplay_row_len"].argtypes = [vp]
     f["selfplay_rows"].argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int32]
     f["selfplay_stats"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    f["mlp_eval"].argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return f
 
 
@@ -302,6 +303,18 @@ class Engine:
         dist = np.empty((self.n_trees, self.n_dist), np.float32)
         self._check(self._f["root_eval"](self._h, _ptr(value, C.c_float), _ptr(dist, C.c_float)))
         return value, dist
+
+    def mlp_eval(self, obs):
+        """Batched network inference (policies.py predict_V / predict_pi / forward) of observations [n, obs_dim] with the
+        search's own arithmetic: (value [n], dist [n, n_dist], raw head outputs [n, 1 + n_dist])."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1, self.s_obs)
+        n = obs.shape[0]
+        value = np.empty((n,), np.float32)
+        dist = np.empty((n, self.n_dist), np.float32)
+        raw = np.empty((n, 1 + self.n_dist), np.float32)
+        self._check(self._f["mlp_eval"](self._h, _ptr(obs, C.c_float), n, _ptr(value, C.c_float), _ptr(dist, C.c_float),
+                                        _ptr(raw, C.c_float)))
+        return value, dist, raw
 
     def dump_tree(self):
         B, R = self.n_trees, self.max_records

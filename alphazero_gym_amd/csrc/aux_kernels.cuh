@@ -201,6 +201,7 @@ __global__ void math_selftest_kernel(int fn_id, const double* in, double* out, s
         case 9: out[i] = (double)((float)x / 3.0f); break;
         case 10: out[i] = (double)__builtin_sqrtf((float)x); break;
         case 11: out[i] = x / 3.0; break;
+        case 12: out[i] = __builtin_sqrt(x); break;
         default: out[i] = 0.0;
     }
 }

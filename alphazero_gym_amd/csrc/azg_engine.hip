@@ -43,6 +43,22 @@ static int fail(azg_engine* e, int code, const std::string& msg) {
         if (_rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(_rc)); \
     } while (0)
 
+// Every entry point works on the engine's device and leaves the caller's current HIP device as it found it (PyTorch and
+// other engines in the same process keep theirs).
+struct DeviceScope {
+    int prev;
+    bool ok;
+    explicit DeviceScope(int dev) : prev(-1) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(e)                                     \
+    DeviceScope _scope((e)->cfg.device_id);              \
+    if (!_scope.ok) return fail(e, AZG_E_DEVICE, "hipSetDevice failed")
+
 template <typename T>
 static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
     void* q = nullptr;
@@ -73,9 +89,13 @@ static int ls_prepare(azg_engine* e) {
     return AZG_OK;
 }
 
+static int env_digit(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && v[0] >= '0' && v[0] <= '9') ? v[0] - '0' : dflt;
+}
+
 static bool use_lockstep(const azg_engine* e) {
-    const char* force = getenv("AZG_FORCE_PERSISTENT");
-    if (force && force[0] == '1') return false;
+    if (e->opt.force_persistent) return false;
     return e->HP >= 512 && e->n_hidden >= 2 && !e->P.layernorm;
 }
 
@@ -87,10 +107,12 @@ const char* azg_last_error(const azg_engine* e) { return e ? e->err.c_str() : g_
 
 void azg_engine_destroy(azg_engine* e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device_id);
+    DeviceScope scope(e->cfg.device_id);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->dev_allocs) (void)hipFree(p);
-    for (void* p : e->weight_allocs) (void)hipFree(p);
+    for (void* p : e->dist_allocs) (void)hipFree(p);
+    if (e->d_wblob) (void)hipFree(e->d_wblob);
+    if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -114,6 +136,16 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, AZG_E_DEVICE, "device_id out of range");
     azg_engine* e = new azg_engine();
     e->cfg = *cfg;
+    e->opt.force_persistent = env_digit("AZG_FORCE_PERSISTENT", 0) == 1;
+    e->opt.force_stream_weights = env_digit("AZG_FORCE_STREAM_WEIGHTS", 0) == 1;
+    e->opt.force_global_tree = env_digit("AZG_FORCE_GLOBAL_TREE", 0) == 1;
+    e->opt.waves = env_digit("AZG_WAVES", 0);
+    e->opt.groups = env_digit("AZG_GROUPS", 0);
+    e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
+    e->opt.ls_graph = env_digit("AZG_LS_GRAPH", 1);
+    e->carry_max = 0;
+    e->d_wblob = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
+    e->d_eval = nullptr; e->eval_floats = 0;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
@@ -139,11 +171,13 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     }
     if (e->R > 32767) { delete e; return fail(nullptr, AZG_E_UNSUPPORTED, "tree too large: records per tree must be < 32768"); }
     e->Kp = (e->Kmax + 15) / 16 * 16;
-    // sqrt(n+1) table: node visit counts reach n_sims (+ the carried root count in discrete mode, <= 3 n_sims)
+    // sqrt(n+1) table: node visit counts reach n_sims (+ the carried root count in discrete mode; beyond 3 n_sims the kernel
+    // computes the root's square root in place)
     e->tab_n = cfg->mode == AZG_MODE_CONTINUOUS ? ns + 2 : 4 * ns + 4;
     e->tree_lds = 0;
     e->dyn_lds = 0;
-    if (hipSetDevice(cfg->device_id) != hipSuccess) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
+    DeviceScope scope(cfg->device_id);
+    if (!scope.ok) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
     e->waves = 4; e->groups = 1; e->n_cus = 256;
     (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
@@ -231,10 +265,11 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     const int HP = pad64(hmax);
     if (HP != 64 && HP != 128 && HP != 256 && HP != 512 && HP != 1024)
         return fail(e, AZG_E_UNSUPPORTED, "hidden width (padded to a multiple of 64) must be one of 64,128,256,512,1024");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    for (void* p : e->weight_allocs) (void)hipFree(p);
-    e->weight_allocs.clear();
+    // nothing below may leave a half-updated weight set usable: the flag goes up again only on success
+    e->mlp_ready = 0;
+    e->results_valid = 0;
     const int NT = HP / 16, S4 = HP / 16;
     // unpack the torch-layout blob into zero-padded [HP][Kp] matrices
     std::vector<std::vector<float>> Wd(d->n_hidden), bd(d->n_hidden), gd(d->n_hidden), ed(d->n_hidden);
@@ -268,83 +303,91 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         for (int kk = 0; kk < kt; ++kk) Wh[(size_t)(1 + o) * HP + kk] = p[(size_t)o * kt + kk];
     p += (size_t)d->n_dist * kt;
     for (int o = 0; o < d->n_dist; ++o) bh[1 + o] = p[o];
+    // All re-laid-out tensors go into ONE host staging vector and ONE device buffer (one H2D copy per weight sync; the buffer
+    // is reused while the network shape stays the same, i.e. across every optimiser step of a training run).
     // MFMA operand layouts (lane l: row/col = l & 15, k-slot g = l >> 4; D register r of tile t = unit 16t + 4g + r)
-    std::vector<float> W0s((size_t)NT * 64), b0s((size_t)NT * 64 * 4);
+    std::vector<float>& st = e->w_stage;
+    st.clear();
+    auto reserve = [&](size_t n) { size_t off = st.size(); st.resize(off + (n + 63) / 64 * 64, 0.0f); return off; };   // 256-byte aligned
+    const size_t oW0 = reserve((size_t)NT * 64), ob0 = reserve((size_t)NT * 64 * 4);
     for (int t = 0; t < NT; ++t)
         for (int l = 0; l < 64; ++l) {
             int row = 16 * t + (l & 15), g = l >> 4;
-            W0s[(size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
-            for (int r = 0; r < 4; ++r) b0s[((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
+            st[oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
+            for (int r = 0; r < 4; ++r) st[ob0 + ((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
         }
-    float *dW0, *db0, *dWh, *dbh;
-    if (dalloc(e, &dW0, W0s.size(), e->weight_allocs)) return AZG_E_DEVICE;
-    if (dalloc(e, &db0, b0s.size(), e->weight_allocs)) return AZG_E_DEVICE;
-    HIPCHK(e, hipMemcpy(dW0, W0s.data(), W0s.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(db0, b0s.data(), b0s.size() * 4, hipMemcpyHostToDevice));
-    e->P.W0 = dW0;
-    e->P.b0 = (const f32x4*)db0;
+    size_t oWl[MAX_STREAM_LAYERS] = {0}, obl[MAX_STREAM_LAYERS] = {0};
     for (int l = 1; l < d->n_hidden; ++l) {
-        std::vector<float> Ws((size_t)NT * S4 * 64 * 4), bs((size_t)NT * 64 * 4);
+        const size_t oW = reserve((size_t)NT * S4 * 64 * 4), ob = reserve((size_t)NT * 64 * 4);
+        oWl[l - 1] = oW; obl[l - 1] = ob;
         for (int t = 0; t < NT; ++t)
             for (int l64 = 0; l64 < 64; ++l64) {
                 int row = 16 * t + (l64 & 15), g = l64 >> 4;
                 for (int s4 = 0; s4 < S4; ++s4)
                     for (int j = 0; j < 4; ++j) {
                         int i = 4 * (4 * s4 + j) + g;   // canonical position consumed by k-slot g of step 4*s4+j
-                        Ws[(((size_t)t * S4 + s4) * 64 + l64) * 4 + j] = Wd[l][(size_t)row * HP + unit_of(i)];
+                        st[oW + (((size_t)t * S4 + s4) * 64 + l64) * 4 + j] = Wd[l][(size_t)row * HP + unit_of(i)];
                     }
-                for (int r = 0; r < 4; ++r) bs[((size_t)t * 64 + l64) * 4 + r] = bd[l][16 * t + 4 * g + r];
+                for (int r = 0; r < 4; ++r) st[ob + ((size_t)t * 64 + l64) * 4 + r] = bd[l][16 * t + 4 * g + r];
             }
-        float *dW, *db;
-        if (dalloc(e, &dW, Ws.size(), e->weight_allocs)) return AZG_E_DEVICE;
-        if (dalloc(e, &db, bs.size(), e->weight_allocs)) return AZG_E_DEVICE;
-        HIPCHK(e, hipMemcpy(dW, Ws.data(), Ws.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(e, hipMemcpy(db, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
-        e->P.Wl[l - 1] = (const f32x4*)dW;
-        e->P.bl[l - 1] = (const f32x4*)db;
     }
-    std::vector<float> Whs((size_t)S4 * 64 * 4);
+    const size_t oWh = reserve((size_t)S4 * 64 * 4), obh = reserve(16);
     for (int s4 = 0; s4 < S4; ++s4)
         for (int l64 = 0; l64 < 64; ++l64) {
             int o = l64 & 15, g = l64 >> 4;
             for (int j = 0; j < 4; ++j) {
                 int i = 4 * (4 * s4 + j) + g;
-                Whs[((size_t)s4 * 64 + l64) * 4 + j] = Wh[(size_t)o * HP + unit_of(i)];
+                st[oWh + ((size_t)s4 * 64 + l64) * 4 + j] = Wh[(size_t)o * HP + unit_of(i)];
             }
         }
-    if (dalloc(e, &dWh, Whs.size(), e->weight_allocs)) return AZG_E_DEVICE;
-    if (dalloc(e, &dbh, (size_t)16, e->weight_allocs)) return AZG_E_DEVICE;
-    HIPCHK(e, hipMemcpy(dWh, Whs.data(), Whs.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(dbh, bh.data(), 16 * 4, hipMemcpyHostToDevice));
-    e->P.Whead = (const f32x4*)dWh;
-    e->P.bhead = dbh;
-    if (e->cfg.mode == AZG_MODE_CONTINUOUS) {
-        // per-node mixture cache and the root-distribution staging buffer are sized by n_dist (the weight set owns them)
-        float* g = nullptr;
-        if (ncomp) { if (dalloc(e, &g, (size_t)e->cfg.n_trees * e->R * 3 * GMM_MAXC, e->weight_allocs)) return AZG_E_DEVICE; }
-        float* rd = nullptr;
-        if (dalloc(e, &rd, (size_t)e->cfg.n_trees * d->n_dist, e->weight_allocs)) return AZG_E_DEVICE;
-        e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
+    for (int o = 0; o < 16; ++o) st[obh + o] = bh[o];
+    size_t olg[MAX_STREAM_LAYERS] = {0}, olb[MAX_STREAM_LAYERS] = {0};
+    if (d->layernorm)
+        for (int l = 0; l < d->n_hidden; ++l) {
+            olg[l] = reserve((size_t)NT * 64 * 4); olb[l] = reserve((size_t)NT * 64 * 4);
+            for (int t = 0; t < NT; ++t)
+                for (int l64 = 0; l64 < 64; ++l64)
+                    for (int r = 0; r < 4; ++r) {
+                        st[olg[l] + ((size_t)t * 64 + l64) * 4 + r] = gd[l][16 * t + 4 * (l64 >> 4) + r];
+                        st[olb[l] + ((size_t)t * 64 + l64) * 4 + r] = ed[l][16 * t + 4 * (l64 >> 4) + r];
+                    }
+        }
+    if (st.size() != e->w_floats || !e->d_wblob) {
+        if (e->d_wblob) (void)hipFree(e->d_wblob);
+        e->d_wblob = nullptr; e->w_floats = 0;
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, st.size() * sizeof(float)));
+        e->d_wblob = (float*)q; e->w_floats = st.size();
     }
+    HIPCHK(e, hipMemcpy(e->d_wblob, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* wb = e->d_wblob;
+    e->P.W0 = wb + oW0;
+    e->P.b0 = (const f32x4*)(wb + ob0);
+    for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {
+        const bool on = l + 1 < d->n_hidden;
+        e->P.Wl[l] = on ? (const f32x4*)(wb + oWl[l]) : nullptr;
+        e->P.bl[l] = on ? (const f32x4*)(wb + obl[l]) : nullptr;
+    }
+    e->P.Whead = (const f32x4*)(wb + oWh);
+    e->P.bhead = wb + obh;
     e->P.layernorm = d->layernorm ? 1 : 0;
-    for (int l = 0; l < d->n_hidden; ++l) {
-        e->P.Htrue[l] = d->hidden[l];
-        e->P.lng[l] = nullptr; e->P.lnb[l] = nullptr;
-        if (!d->layernorm) continue;
-        std::vector<float> gs((size_t)NT * 64 * 4), es((size_t)NT * 64 * 4);
-        for (int t = 0; t < NT; ++t)
-            for (int l64 = 0; l64 < 64; ++l64)
-                for (int r = 0; r < 4; ++r) {
-                    gs[((size_t)t * 64 + l64) * 4 + r] = gd[l][16 * t + 4 * (l64 >> 4) + r];
-                    es[((size_t)t * 64 + l64) * 4 + r] = ed[l][16 * t + 4 * (l64 >> 4) + r];
-                }
-        float *dg, *de;
-        if (dalloc(e, &dg, gs.size(), e->weight_allocs)) return AZG_E_DEVICE;
-        if (dalloc(e, &de, es.size(), e->weight_allocs)) return AZG_E_DEVICE;
-        HIPCHK(e, hipMemcpy(dg, gs.data(), gs.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(e, hipMemcpy(de, es.data(), es.size() * 4, hipMemcpyHostToDevice));
-        e->P.lng[l] = (const f32x4*)dg;
-        e->P.lnb[l] = (const f32x4*)de;
+    for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {
+        e->P.Htrue[l] = l < d->n_hidden ? d->hidden[l] : 0;
+        e->P.lng[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + olg[l]) : nullptr;
+        e->P.lnb[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + olb[l]) : nullptr;
+    }
+    if (e->cfg.mode == AZG_MODE_CONTINUOUS && (d->n_dist != e->dist_nd || ncomp != e->dist_ncomp)) {
+        // the per-node mixture cache and the root-distribution staging buffer are sized by the head: rebuilt only when it changes
+        // (the last search's cached distributions go with them)
+        for (void* q : e->dist_allocs) (void)hipFree(q);
+        e->dist_allocs.clear();
+        e->dist_nd = -1; e->searched = 0;
+        float* g = nullptr;
+        if (ncomp) { if (dalloc(e, &g, (size_t)e->cfg.n_trees * e->R * 3 * GMM_MAXC, e->dist_allocs)) return AZG_E_DEVICE; }
+        float* rd = nullptr;
+        if (dalloc(e, &rd, (size_t)e->cfg.n_trees * d->n_dist, e->dist_allocs)) return AZG_E_DEVICE;
+        e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
+        e->dist_nd = d->n_dist; e->dist_ncomp = ncomp;
     }
     e->HP = HP; e->n_hidden = d->n_hidden; e->n_out = n_out; e->act = d->activation;
     e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
@@ -354,8 +397,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     e->nreg = (nhh >= 1 && nhh <= 3 && regs <= 288) ? nhh : 0;
     // LayerNorm and the rare activations live in the weight-streaming kernels only (keeps the register-resident kernels lean)
     if (d->layernorm || (d->activation != AZG_ACT_RELU && d->activation != AZG_ACT_ELU)) e->nreg = 0;
-    const char* force = getenv("AZG_FORCE_STREAM_WEIGHTS");
-    if (force && force[0] == '1') e->nreg = 0;
+    if (e->opt.force_stream_weights) e->nreg = 0;
     e->mlp_ready = 1;
     return AZG_OK;
 }
@@ -373,10 +415,14 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
                 return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         }
     }
+    int cmax = 0;
     if (carry)
-        for (int i = 0; i < B; ++i)
-            if (carry[i] < 0 || carry[i] > 3 * e->cfg.n_sims) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+        for (int i = 0; i < B; ++i) {
+            if (carry[i] < 0 || carry[i] > (1 << 30)) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
+            if (carry[i] > cmax) cmax = carry[i];
+        }
+    e->carry_max = cmax;
+    ON_DEVICE(e);
     HIPCHK(e, hipMemcpyAsync(e->d_roots, roots, sizeof(double) * (size_t)B * S, hipMemcpyHostToDevice, e->stream));
     if (carry) HIPCHK(e, hipMemcpyAsync(e->d_carry, carry, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, e->stream));
     else HIPCHK(e, hipMemsetAsync(e->d_carry, 0, sizeof(int) * (size_t)B, e->stream));
@@ -387,7 +433,7 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
 int azg_search_resident(azg_engine* e) {
     if (!e) return AZG_E_INVALID;
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     e->P.search_idx = e->search_idx;
     const bool lockstep = use_lockstep(e);
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
@@ -407,7 +453,7 @@ int azg_search_resident(azg_engine* e) {
 
 int azg_sync(azg_engine* e) {
     if (!e) return AZG_E_INVALID;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return AZG_OK;
 }
@@ -423,7 +469,7 @@ int azg_search(azg_engine* e, const double* roots, const int32_t* carry) {
 int azg_last_search_ms(azg_engine* e, float* ms) {
     if (!e || !ms) return AZG_E_INVALID;
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipEventSynchronize(e->ev1));
     HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
     return AZG_OK;
@@ -432,7 +478,7 @@ int azg_last_search_ms(azg_engine* e, float* ms) {
 static int gather_results(azg_engine* e) {
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     if (e->results_valid) return AZG_OK;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     int B = e->cfg.n_trees;
     hipLaunchKernelGGL(results_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
                        e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
@@ -477,11 +523,40 @@ int azg_root_eval(azg_engine* e, float* value, float* dist) {
     return AZG_OK;
 }
 
+int azg_mlp_eval(azg_engine* e, const float* obs, size_t n, float* value, float* dist, float* raw) {
+    if (!e || !obs) return AZG_E_INVALID;
+    if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
+    if (n == 0) return AZG_OK;
+    if (n > (size_t)1 << 24) return fail(e, AZG_E_INVALID, "too many observations in one call");
+    ON_DEVICE(e);
+    const size_t So = e->S_obs, nd = e->nd;
+    const size_t need = n * (So + 1 + nd + 1 + nd);
+    if (need > e->eval_floats) {
+        if (e->d_eval) (void)hipFree(e->d_eval);
+        e->d_eval = nullptr; e->eval_floats = 0;
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, need * sizeof(float)));
+        e->d_eval = (float*)q; e->eval_floats = need;
+    }
+    float* d_obs = e->d_eval;
+    float* d_v = d_obs + n * So;
+    float* d_d = d_v + n;
+    float* d_r = d_d + n * nd;
+    HIPCHK(e, hipMemcpyAsync(d_obs, obs, n * So * 4, hipMemcpyHostToDevice, e->stream));
+    hipError_t rc = azg_dispatch_mlp_eval(e, d_obs, (int)n, d_v, d_d, d_r);
+    if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("mlp_eval kernel launch: ") + hipGetErrorString(rc));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    D2H(value, d_v, n * 4);
+    D2H(dist, d_d, n * nd * 4);
+    D2H(raw, d_r, n * (nd + 1) * 4);
+    return AZG_OK;
+}
+
 int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* edge_n, double* edge_W, double* edge_Q,
                   float* edge_action, int32_t* node_n, double* node_r, float* node_V, uint8_t* node_flags) {
     if (!e) return AZG_E_INVALID;
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     size_t B = e->cfg.n_trees, R = e->R;
     std::vector<RecL> hot(B * R);
@@ -522,7 +597,7 @@ int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
     size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 4;
     if (rows > max_rows) rows = max_rows;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, e->P.stamps, rows * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return (int)rows;
@@ -544,7 +619,7 @@ int azg_selfplay_row_len(const azg_engine* e) { return e ? e->S_obs + 3 * e->Kma
 
 int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
     if (!e || max_episode_length < 1 || capacity_steps < 1) return AZG_E_INVALID;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (void* p : e->sp_allocs) (void)hipFree(p);
     e->sp_allocs.clear();
@@ -590,7 +665,7 @@ int azg_selfplay_step(azg_engine* e) {
 int azg_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear) {
     if (!e) return AZG_E_INVALID;
     if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     size_t n = (size_t)e->sp_steps * e->cfg.n_trees;
     if (n > max_rows) n = max_rows;
@@ -602,7 +677,7 @@ int azg_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear
 int azg_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_state) {
     if (!e) return AZG_E_INVALID;
     if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     size_t B = e->cfg.n_trees;
     D2H(fsum, e->d_sp_fsum, B * 8);
@@ -613,7 +688,8 @@ int azg_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_s
 
 int azg_math_selftest(int device_id, int fn_id, const double* in, double* out, size_t n) {
     if (!in || !out || n == 0) return AZG_E_INVALID;
-    if (hipSetDevice(device_id) != hipSuccess) return AZG_E_DEVICE;
+    DeviceScope scope(device_id);
+    if (!scope.ok) return AZG_E_DEVICE;
     double *di = nullptr, *dout = nullptr;
     if (hipMalloc((void**)&di, n * 8) != hipSuccess) return AZG_E_DEVICE;
     if (hipMalloc((void**)&dout, n * 8) != hipSuccess) { (void)hipFree(di); return AZG_E_DEVICE; }

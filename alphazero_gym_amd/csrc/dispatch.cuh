@@ -1,6 +1,7 @@
 // dispatch.cuh -- host-side choice and launch of the persistent search kernel variants (included by the dispatch_*.hip
 // translation units, each of which instantiates one family of them).
 #pragma once
+#include <atomic>
 #include <cstdlib>
 
 #include "engine_host.h"
@@ -14,12 +15,14 @@
 template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
 static hipError_t launch_g(azg_engine* e) {
     auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
-    static int static_lds = -1;
+    static std::atomic<int> static_lds_cache{-1};   // per kernel variant; engines of several host threads may race to fill it
+    int static_lds = static_lds_cache.load(std::memory_order_relaxed);
     if (static_lds < 0) {
         hipFuncAttributes fa;
         hipError_t rc = hipFuncGetAttributes(&fa, (const void*)kern);
         if (rc != hipSuccess) return rc;
         static_lds = (int)fa.sharedSizeBytes;
+        static_lds_cache.store(static_lds, std::memory_order_relaxed);
     }
     const LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, ENV != AZG_ENV_CARTPOLE, TLDS);
     if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
@@ -53,22 +56,21 @@ template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {
     const int ns = e->cfg.n_sims;
     // LDS trees: <= 16 children per node; 8-bit ids / 16-bit counts up to 255 records, 9-bit ids / 11-bit counts up to 511
+    // (node counts: the root's is the largest, carried count + n_sims)
     int ts = TS_GLOBAL;
+    const long nmax = (long)e->carry_max + ns + 2;
     if (e->Kp == 16) {
-        if (e->R <= 255 && 4 * ns + 4 < 65536) ts = TS_LDS8;
-        else if (e->R <= 511 && 4 * ns + 4 < 2048) ts = TS_LDS9;
+        if (e->R <= 255 && nmax < 65536) ts = TS_LDS8;
+        else if (e->R <= 511 && nmax < 2048) ts = TS_LDS9;
     }
-    const char* force = getenv("AZG_FORCE_GLOBAL_TREE");
-    if (force && force[0] == '1') ts = TS_GLOBAL;
+    if (e->opt.force_global_tree) ts = TS_GLOBAL;
     if constexpr (HP == 256 && NREG == 1) {
-        const char* w = getenv("AZG_WAVES");
-        const char* g = getenv("AZG_GROUPS");
         bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
-        if (g && g[0] == '2') two = true;
-        if (g && g[0] == '1') two = false;
+        if (e->opt.groups == 2) two = true;
+        if (e->opt.groups == 1) two = false;
         bool want8 = two;
-        if (w && w[0] == '8') want8 = true;
-        if (w && w[0] == '4') want8 = false;
+        if (e->opt.waves == 8) want8 = true;
+        if (e->opt.waves == 4) want8 = false;
         if (want8 && ts == TS_LDS8 && e->P.ncomp < 2) {
             hipError_t rc = hipErrorInvalidConfiguration;
             if (two) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 2>(e);

@@ -9,8 +9,21 @@
 
 #include "records.h"
 
+// diagnostic switches (environment variables, read once when the engine is created): force the other code paths in tests
+struct EngineOptions {
+    int force_persistent;      // AZG_FORCE_PERSISTENT=1: wide networks on the one-launch kernel instead of the lock-step path
+    int force_stream_weights;  // AZG_FORCE_STREAM_WEIGHTS=1: hidden->hidden weights streamed from L2 instead of register-resident
+    int force_global_tree;     // AZG_FORCE_GLOBAL_TREE=1: trees in global memory instead of LDS
+    int waves;                 // AZG_WAVES=4|8 (0: automatic)
+    int groups;                // AZG_GROUPS=1|2 (0: automatic)
+    int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
+    int ls_graph;              // AZG_LS_GRAPH=0: plain launches instead of a captured hipGraph on the lock-step path
+};
+
 struct azg_engine {
     azg_config cfg;
+    EngineOptions opt;
+    int carry_max;           // largest carried root visit count of the uploaded roots
     int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
     int mlp_ready, HP, n_hidden, n_out, act, nreg;
     int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
@@ -21,7 +34,11 @@ struct azg_engine {
     hipEvent_t ev0, ev1;
     KParams P;
     std::vector<void*> dev_allocs;
-    std::vector<void*> weight_allocs;
+    float* d_wblob;          // every re-laid-out weight tensor of the current network in one buffer (reused while the shape stays)
+    size_t w_floats;
+    std::vector<float> w_stage;      // host staging of that buffer
+    std::vector<void*> dist_allocs;  // continuous mode: per-node mixture cache + root distribution staging, sized by the head
+    int dist_nd, dist_ncomp;
     // results staging
     float* d_actions; int* d_counts; double* d_Q; double* d_vt; int* d_nch; int* d_child_n; double* d_child_state;
     float* d_rootV; float* d_rootdist;
@@ -34,6 +51,7 @@ struct azg_engine {
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;
+    float* d_eval; size_t eval_floats;   // scratch of azg_mlp_eval (grow-only)
     int searched, results_valid;
     float last_ms;
     std::string err;
@@ -45,3 +63,5 @@ hipError_t azg_dispatch_pendulum_small(azg_engine* e);   // hidden width (padded
 hipError_t azg_dispatch_pendulum_large(azg_engine* e);   // 256 and wider
 hipError_t azg_ls_dispatch_cartpole(azg_engine* e);      // lock-step path (lockstep.cuh), buffers prepared by the caller
 hipError_t azg_ls_dispatch_pendulum(azg_engine* e);
+// batched network inference of n observations (device pointers) on e->stream (mlp_eval.cuh)
+hipError_t azg_dispatch_mlp_eval(azg_engine* e, const float* obs, int n, float* value, float* dist, float* raw);

@@ -25,8 +25,7 @@ static hipError_t ls_run(azg_engine* e) {
     auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
     const int TQ = (G + 1) / 2, NU = HP / 64;
     const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
-    const char* tenv = getenv("AZG_LS_TILED");
-    const bool tiled = !(tenv && tenv[0] == '0');
+    const bool tiled = e->opt.ls_tiled != 0;
     if (tiled) {
         hipError_t rc = hipFuncSetAttribute((const void*)tkh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
         if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);

@@ -165,7 +165,11 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
             if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
         }
-        const double sq = s_sqrt[hp.node_n];
+        // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
+        // carry a count beyond the table, then the correctly rounded square root is computed in place
+        double sq;
+        if (CONT || (int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
+        else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
         int win_c = 0;
         if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
             // the common case: all children fit one 16-lane row

@@ -49,11 +49,14 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0) -> None:
     """Rank `src` trained; everyone else receives the parameters (one flat buffer: KBs to a few MB, latency-bound)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    params: List[torch.Tensor] = [p.data for p in model.parameters()]
-    flat = torch.cat([p.reshape(-1) for p in params])
+    params: List[torch.Tensor] = list(model.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
     dist.broadcast(flat, src=src)
     off = 0
-    for p in params:
-        n = p.numel()
-        p.copy_(flat[off:off + n].view_as(p))
-        off += n
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            # in-place copy INTO the Parameter (not its .data alias): bumps Parameter._version, which is what
+            # BatchedMCTS.sync_weights watches to decide whether the engine needs the new weights
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n

@@ -34,7 +34,27 @@ def env_signature(env) -> Tuple[int, np.ndarray]:
 
 
 def _weights_version(model) -> Tuple:
-    return tuple((id(p), p._version) for p in model.parameters())
+    """Changes whenever a parameter is written in place (optimiser step, copy_, broadcast: ``_version``) or rebound to
+    new storage (``p.data = ...``, ``load_state_dict(assign=True)``: ``data_ptr``)."""
+    return tuple((id(p), p._version, p.data_ptr()) for p in model.parameters())
+
+
+def device_ordinal(device) -> int:
+    """GPU ordinal for the reference's ``device`` kwarg (mcts.py:316-327).  "cuda:N" -> N; "cuda" -> torch's current device;
+    anything else (the reference's configs say "cpu": that is where ITS network ran) -> LOCAL_RANK, so that one agent per
+    rank lands on its own GPU, else 0."""
+    import os
+    try:
+        import torch
+        d = torch.device(device) if device is not None else None
+        if d is not None and d.type == "cuda":
+            if d.index is not None:
+                return int(d.index)
+            if torch.cuda.is_available():
+                return int(torch.cuda.current_device())
+    except (RuntimeError, TypeError):
+        pass
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 class BatchedMCTS:
@@ -112,14 +132,16 @@ class MCTS:
         raise NotImplementedError
 
     def _ensure_engine(self, env_id: int, n_trees: int) -> BatchedMCTS:
+        device_id = device_ordinal(self.device)
         key = (env_id, n_trees, self.n_rollouts, self.c_uct, self.gamma, self.epsilon, self.V_target_policy, id(self.model),
-               tuple(sorted(self._engine_kwargs().items())))
+               device_id, tuple(sorted(self._engine_kwargs().items())))
         if self._batched is None or key != self._key:
             if self._batched is not None:
                 self._batched.close()
             self._batched = BatchedMCTS(self.model, env_id=env_id, mode=self._mode, n_trees=n_trees, n_rollouts=self.n_rollouts,
                                         c_uct=self.c_uct, gamma=self.gamma, epsilon=self.epsilon,
-                                        V_target_policy=self.V_target_policy, seed=self.seed, **self._engine_kwargs())
+                                        V_target_policy=self.V_target_policy, seed=self.seed, device_id=device_id,
+                                        **self._engine_kwargs())
             self._key = key
         return self._batched
 

@@ -116,6 +116,13 @@ int azg_root_children(azg_engine* e, int32_t* child_n, double* child_state);
  * (continuous: mu.., sigma..; discrete: softmax priors). For MLP parity tests. */
 int azg_root_eval(azg_engine* e, float* value, float* dist);
 
+/* Batched network inference without a search: Policy.predict_V / DiscretePolicy.predict_pi / DiagonalNormalPolicy.forward /
+ * DiagonalGMMPolicy.forward (policies.py:150-160, 340-352, 436-464, 544-560) for n observations at once, with exactly the
+ * arithmetic a search uses for its leaves.  obs [n][obs_dim] float32 (host); value [n]; dist [n][n_dist] (discrete: softmax
+ * priors; Normal: mu, sigma; mixture: mu_c.., sigma_c.., cumulative mixture probabilities); raw [n][1 + n_dist] = the
+ * value head and the untransformed distribution head (logits / mu, log_std).  Output pointers may be NULL. */
+int azg_mlp_eval(azg_engine* e, const float* obs, size_t n, float* value, float* dist, float* raw);
+
 /* whole-tree dump for bit-exact parity tests: per tree the node/edge records in creation order.
  * See DESIGN.md "record layout". rec_* arrays are [B][azg_max_records()]; n_records [B]. */
 int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* edge_n, double* edge_W, double* edge_Q,

@@ -589,7 +589,7 @@ int azo_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
     for (int i = 0; i < e->cfg.n_trees; ++i) {
         if (env_root_terminal(e->cfg.env_id, roots + (size_t)i * e->S_env))
             return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
-        if (carry && (carry[i] < 0 || carry[i] > 3 * e->cfg.n_sims)) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
+        if (carry && (carry[i] < 0 || carry[i] > (1 << 30))) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
     }
     memcpy(e->roots, roots, sizeof(double) * (size_t)e->cfg.n_trees * e->S_env);
     if (carry) memcpy(e->carry, carry, 4 * (size_t)e->cfg.n_trees); else memset(e->carry, 0, 4 * (size_t)e->cfg.n_trees);
@@ -851,6 +851,7 @@ int azo_math_eval(int fn_id, const double* in, double* out, size_t n) {
             case 9: out[i] = (double)((float)x / 3.0f); break;
             case 10: out[i] = (double)__builtin_sqrtf((float)x); break;
             case 11: out[i] = x / 3.0; break;
+            case 12: out[i] = sqrt(x); break;
             default: return AZG_E_INVALID;
         }
     }

@@ -48,7 +48,6 @@ def lib():
         _lib.azo_gmm_u.restype = C.c_float
         _lib.azo_sample_action.restype = C.c_float
         _lib.azo_math_eval.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
-        _lib.azo_mlp_eval.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib.azo_env_step.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         _lib.azo_env_obs.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
@@ -63,17 +62,6 @@ def fns():
 class OracleEngine(_capi.Engine):
     def __init__(self, **kw):
         super().__init__(fns(), **kw)
-
-    def mlp_eval(self, obs):
-        obs = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1, self.s_obs)
-        n = obs.shape[0]
-        value = np.empty((n,), np.float32)
-        dist = np.empty((n, self.n_dist), np.float32)
-        raw = np.empty((n, 1 + self.n_dist), np.float32)
-        rc = lib().azo_mlp_eval(self._h, _capi._ptr(obs, C.c_float), n, _capi._ptr(value, C.c_float),
-                                _capi._ptr(dist, C.c_float), _capi._ptr(raw, C.c_float))
-        assert rc == 0, rc
-        return value, dist, raw
 
 
 def normal(seed, tree, search, draw):

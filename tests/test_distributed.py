@@ -78,12 +78,17 @@ def test_two_rank_selfplay_equals_single_process():
     np.testing.assert_array_equal(c_.sum(1), np.full(B_TOTAL, N_SIMS))
 
 
-def _train_worker(rank, world, port, q):
-    """examples/selfplay_train.py in its multi-rank form (gloo here, RCCL on the GPU box), engine = the oracle test double"""
+def _train_worker(rank, world, port, q, hip=False):
+    """examples/selfplay_train.py in its multi-rank form (gloo here, RCCL on the GPU box), engine = the oracle test double
+    (CPU suite) or the HIP engine with both ranks on GPU 0 (-m gpu)"""
     import importlib.util
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0" if hip else str(rank))
     from alphazero_gym_amd import _native
-    _native.HipEngine = O.OracleEngine
+    if hip:
+        _native.lib()
+    else:
+        _native.HipEngine = O.OracleEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "selfplay_train.py")
     spec = importlib.util.spec_from_file_location("selfplay_train", path)
@@ -100,26 +105,48 @@ def _train_worker(rank, world, port, q):
         return agent, sd
 
     mod.build_agent = build
+    orig_sp = mod.run.DeviceSelfPlay
+
+    def selfplay(*a, **k):
+        captured["sp"] = orig_sp(*a, **k)
+        return captured["sp"]
+
+    mod.run.DeviceSelfPlay = selfplay
     hist = mod.train(args, log=None)
     flat = torch.cat([p.detach().reshape(-1) for p in captured["agent"].nn.parameters()])
-    q.put((rank, hist, float(flat.double().sum()), float(flat.abs().double().sum())))
+    # what the ENGINE evaluates with, not just what torch holds: the ordinary (non-forced) weight sync of the next collect(),
+    # then the root value of the same states on every rank
+    sp = captured["sp"]
+    sp.mcts.sync_weights()
+    probe = np.tile(np.array([[0.01, -0.02, 0.03, 0.04]]), (8, 1)) * (0.5 * np.arange(1, 9))[:, None]
+    sp.engine.search(probe)
+    v_engine, _ = sp.engine.root_eval()
+    with torch.no_grad():
+        v_torch = captured["agent"].nn(torch.from_numpy(probe.astype(np.float32)))[1].reshape(-1).numpy()
+    q.put((rank, hist, float(flat.double().sum()), float(flat.abs().double().sum()), v_engine.tolist(), v_torch.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_training_loop_keeps_weights_in_sync():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("hip", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["oracle_double", "hip"])
+def test_two_rank_training_loop_keeps_weights_in_sync(hip):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, hip)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, h0, s0, a0), (_, h1, s1, a1) = got
+    (_, h0, s0, a0, ve0, vt0), (_, h1, s1, a1, ve1, vt1) = got
     assert s0 == s1 and a0 == a1 and np.isfinite(s0)                     # rank 0 trained, rank 1 received the same weights
+    assert ve0 == ve1                                                    # ... and both ENGINES search with them
+    np.testing.assert_allclose(ve1, vt1, atol=1e-5, rtol=1e-5)           # (the broadcast must reach the engine of every rank)
     assert len(h0) == 3 and h0[-1]["env_steps"] == 3 * 6 * 8 * 2         # both ranks' games counted
     keys = ("iter", "episodes_finished", "mean_return", "env_steps")
     assert [[h[k] for k in keys] for h in h0] == [[h[k] for k in keys] for h in h1]   # all-reduced episode statistics agree

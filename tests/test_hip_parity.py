@@ -21,6 +21,7 @@ MATH_INPUTS = {
     3: np.linspace(1e-8, 1.0, 20001), 4: np.linspace(0, 0.99999, 20001), 5: np.linspace(-100, 100, 20001),
     6: np.linspace(-100, 100, 20001), 7: np.linspace(-100, 100, 20001), 8: np.arange(20001, dtype=np.float64),
     9: np.linspace(-50, 50, 20001), 10: np.linspace(0, 50, 20001), 11: np.linspace(-50, 50, 20001),
+    12: np.concatenate([np.arange(1, 20001, dtype=np.float64), np.linspace(2e4, 2e9, 20001)]),   # sqrt(n + 1) beyond the host table
 }
 
 
@@ -162,6 +163,27 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     _assert_same(a, b)
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_carried_root_counts_beyond_the_sqrt_table(native, big):
+    """A reused root searched again and again without moving on (legal in the reference: act() twice on one state) carries a
+    visit count beyond the host-built sqrt(n + 1) table (4 n_sims + 4 entries): the kernel then computes the root's square root
+    in place.  `big`: counts that no longer fit the 16-bit LDS records -> global-memory trees."""
+    NS, B = 40, 19
+    kw = dict(env_id=0, mode=0, n_trees=B, n_sims=NS, c_uct=30.0, gamma=0.98, num_actions=2, seed=5, tree_id_base=3)
+    desc = _capi.make_desc(4, [64, 64], 2, "relu")
+    blob = O.make_weights(9, 4, [64, 64], 2, scale=2.0)
+    o = O.OracleEngine(**kw)
+    roots = o.synthetic_roots()
+    o.close()
+    carry = (np.arange(B) * 37 % 400).astype(np.int32)       # 4 * NS + 4 = 164: both sides of the table's end
+    if big:
+        carry[::3] += 70000
+    a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=1)
+    b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=1)
+    _assert_same(a, b)
+    np.testing.assert_array_equal(a[1]["node_n"][:, 0], carry + NS)
+
+
 def test_terminal_root_raises(native):
     e = native.HipEngine(env_id=0, mode=0, n_trees=2, n_sims=4, c_uct=1.5, gamma=1.0, num_actions=2)
     e.set_weights(_capi.make_desc(4, [64], 2, "relu"), O.make_weights(1, 4, [64], 2))
@@ -205,6 +227,105 @@ def test_full_size_properties(native, B):
         np.testing.assert_array_equal(do["edge_W"][0], d["edge_W"][t])
         oo.close()
     e.close()
+
+
+def _tree_invariants(r, d, NS, trees):
+    assert (r["counts"].sum(1) == NS).all()                       # sum of root counts == n_sims
+    assert (d["n_records"] == NS + 1).all()                       # one new node per trace (Pendulum never terminates)
+    assert (d["node_n"][:, 0] == NS).all()
+    for t in trees:                                               # node.n == sum of child edge counts, for every node
+        par, en, nn = d["parent"][t], d["edge_n"][t], d["node_n"][t]
+        acc = np.zeros_like(nn)
+        np.add.at(acc, par[1:NS + 1], en[1:NS + 1])
+        np.testing.assert_array_equal(acc[:NS + 1], nn[:NS + 1])
+
+
+def _oracle_block(kw, desc, blob, roots, lo, hi):
+    """Trees [lo, hi) of a batch on the oracle (same global tree ids -> same noise), OpenMP over the block's trees."""
+    oo = O.OracleEngine(**dict(kw, n_trees=hi - lo, tree_id_base=kw.get("tree_id_base", 0) + lo))
+    oo.set_weights(desc, blob)
+    oo.search(roots[lo:hi])
+    out = oo.results(), oo.dump_tree()
+    oo.close()
+    return out
+
+
+def test_config_e_full_size_lockstep(native):
+    """BASELINE config E per GPU (Pendulum-v1, 1024 trees, n_sims 200, 4x1024 ELU: mcts.py:656-702 at E's tree sizes) on the
+    lock-step path: 201 simulation steps of tree / layer kernels over global-memory trees.  Size-independent invariants on
+    every tree + 24 trees (both ends and the middle of the batch) bit-exact against the oracle: counts, Q, W, parents."""
+    NS, B = 200, 1024
+    kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+    desc = _capi.make_desc(3, [1024] * 4, 2, "elu")
+    blob = O.make_weights(34, 3, [1024] * 4, 2)
+    e = native.HipEngine(**kw)
+    e.set_weights(desc, blob)
+    roots = e.synthetic_roots()
+    e.search(roots)
+    r, d = e.results(), e.dump_tree()
+    ms = e.last_search_ms()
+    e.close()
+    assert (r["n_children"] == 15).all()
+    _tree_invariants(r, d, NS, range(0, B, 61))
+    depth = np.zeros((B, NS + 1), np.int32)
+    for j in range(1, NS + 1):
+        depth[:, j] = depth[np.arange(B), d["parent"][:, j]] + 1
+    assert depth.max() >= 4, depth.max()                          # real trees: several levels below the root
+    for lo, hi in ((0, 8), (508, 516), (B - 8, B)):
+        ro, do = _oracle_block(kw, desc, blob, roots, lo, hi)
+        for k in ("counts", "Q", "actions", "v_target", "n_children"):
+            np.testing.assert_array_equal(ro[k], r[k][lo:hi], err_msg=k)
+        for k in do:
+            np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=k)
+    assert ms < 40.0, f"config E search took {ms:.1f} ms (measured 16.6 ms in round 1)"
+
+
+def test_config_e_persistent_kernel_equals_lockstep(native, monkeypatch):
+    """The same network and search on the one-launch kernel (AZG_FORCE_PERSISTENT=1; weights streamed from L2) on a smaller batch:
+    identical trees to the lock-step path's, record for record."""
+    NS, B = 200, 80
+    kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34, tree_id_base=512)
+    desc = _capi.make_desc(3, [1024] * 4, 2, "elu")
+    blob = O.make_weights(34, 3, [1024] * 4, 2)
+    e = native.HipEngine(**kw)
+    roots = e.synthetic_roots()
+    e.close()
+    a = _run(native.HipEngine, kw, desc, blob, roots)
+    monkeypatch.setenv("AZG_FORCE_PERSISTENT", "1")
+    b = _run(native.HipEngine, kw, desc, blob, roots)
+    _assert_same(a, b)
+    _tree_invariants(a[0], a[1], NS, range(B))
+    ro, do = _oracle_block(kw, desc, blob, roots, 70, 74)
+    for k in do:
+        np.testing.assert_array_equal(do[k], b[1][k][70:74], err_msg=k)
+
+
+@pytest.mark.parametrize("cfg", ["C", "B"])
+def test_shard_invariance_on_the_device(native, cfg):
+    """SURVEY 4.4 / 8e on the HIP engine: a tree's result depends on its GLOBAL id only.  One engine of 4096 trees (config D's
+    per-GPU leg) == two engines of 2048 trees with tree_id_base 0 and 2048, row for row and record for record."""
+    if cfg == "C":
+        kw = dict(env_id=2, mode=1, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+        desc, blob = _capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2)
+    else:
+        kw = dict(env_id=0, mode=0, n_sims=100, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+        desc, blob = _capi.make_desc(4, [128, 128], 2, "relu"), O.make_weights(34, 4, [128, 128], 2)
+    whole = native.HipEngine(n_trees=4096, **kw)
+    roots = whole.synthetic_roots()
+    whole.close()
+    full = _run(native.HipEngine, dict(kw, n_trees=4096, tree_id_base=0), desc, blob, roots)
+    for lo in (0, 2048):
+        e = native.HipEngine(n_trees=2048, tree_id_base=lo, **kw)
+        np.testing.assert_array_equal(e.synthetic_roots(), roots[lo:lo + 2048])   # synthetic roots are keyed by the global id too
+        e.close()
+        part = _run(native.HipEngine, dict(kw, n_trees=2048, tree_id_base=lo), desc, blob, roots[lo:lo + 2048])
+        for df, dp in zip(full, part):
+            if isinstance(df, dict):
+                for k in df:
+                    np.testing.assert_array_equal(df[k][lo:lo + 2048], dp[k], err_msg=k)
+            else:
+                for x, y in zip(df, dp):
+                    np.testing.assert_array_equal(x[lo:lo + 2048], y)
 
 
 def _random_case(rng):
