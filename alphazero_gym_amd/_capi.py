@@ -66,6 +66,22 @@ class AzgMlpDesc(C.Structure):
     ]
 
 
+class AzgSelfplayConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("max_episode_length", C.c_int32),
+        ("deterministic", C.c_int32),
+        ("capacity_steps", C.c_int32),
+        ("final_selection", C.c_int32),
+        ("ring_mode", C.c_int32),
+        ("temperature", C.c_double),
+        ("agent_epsilon", C.c_double),
+    ]
+
+
+FINAL_SELECTION = {"max_visit": 0, "max_visits": 0, "max_value": 1}   # the reference's configs spell it both ways
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"azgym error {code}: {msg}")
@@ -80,7 +96,8 @@ SYMBOLS = [
     "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_search_index", "search",
     "results", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
     "synthetic_roots", "last_search_ms", "upload_roots", "search_resident", "sync",
-    "selfplay_begin", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats", "mlp_eval",
+    "selfplay_begin", "selfplay_begin_ex", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats",
+    "selfplay_ring", "selfplay_rows_device", "mlp_eval",
 ]
 
 
@@ -113,6 +130,9 @@ def bind(lib, prefix):
     f["search_resident"].argtypes = [vp]
     f["sync"].argtypes = [vp]
     f["selfplay_begin"].argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    f["selfplay_begin_ex"].argtypes = [vp, C.POINTER(AzgSelfplayConfig)]
+    f["selfplay_ring"].argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    f["selfplay_rows_device"].argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     f["selfplay_step"].argtypes = [vp]
     f["selfplay_row_len"].argtypes = [vp]
     f["selfplay_rows"].argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int32]
@@ -339,10 +359,34 @@ class Engine:
 
 
 def _selfplay_methods():
-    def selfplay_begin(self, max_episode_length, deterministic=False, capacity_steps=64):
-        """Start device-resident self-play: games reset to their fixed-seed initial states (include/azgym.h)."""
-        self._check(self._f["selfplay_begin"](self._h, int(max_episode_length), int(bool(deterministic)), int(capacity_steps)))
+    def selfplay_begin(self, max_episode_length, deterministic=False, capacity_steps=64, final_selection="max_visit",
+                       temperature=1.0, agent_epsilon=0.0, fifo=False):
+        """Start device-resident self-play: games reset to their fixed-seed initial states (include/azgym.h).
+        final_selection / temperature / agent_epsilon: the agents' final action rule (agents.py:294-301, 524-535);
+        fifo: the ring overwrites its oldest step like ReplayBuffer.store (buffers.py:75-82) instead of refusing when full."""
+        c = AzgSelfplayConfig()
+        c.struct_size = C.sizeof(AzgSelfplayConfig)
+        c.max_episode_length = int(max_episode_length)
+        c.deterministic = int(bool(deterministic))
+        c.capacity_steps = int(capacity_steps)
+        c.final_selection = FINAL_SELECTION[final_selection] if isinstance(final_selection, str) else int(final_selection)
+        c.ring_mode = 1 if fifo else 0
+        c.temperature = float(temperature)
+        c.agent_epsilon = float(agent_epsilon)
+        self._check(self._f["selfplay_begin_ex"](self._h, C.byref(c)))
         self._sp_cap = int(capacity_steps)
+
+    def selfplay_ring(self):
+        """(size, insert_index, total) of the replay ring in steps: ReplayBuffer.size / .insert_index (buffers.py:56-82)."""
+        size, ins, tot = C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(self._f["selfplay_ring"](self._h, C.byref(size), C.byref(ins), C.byref(tot)))
+        return size.value, ins.value, tot.value
+
+    def selfplay_rows_device(self):
+        """(device pointer, capacity in rows, row length) of the replay ring, for consumers on the same GPU."""
+        ptr, cap, rl = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(self._f["selfplay_rows_device"](self._h, C.byref(ptr), C.byref(cap), C.byref(rl)))
+        return ptr.value, cap.value, rl.value
 
     def selfplay_step(self):
         """One search + final action + env step + bookkeeping for all games, entirely on the device (asynchronous)."""
@@ -357,6 +401,12 @@ def _selfplay_methods():
             self._check(n)
         return rows[:n]
 
+    def selfplay_clear(self):
+        """ReplayBuffer.clear (buffers.py:56-60) for the device ring, without downloading anything."""
+        n = self._f["selfplay_rows"](self._h, None, 0, 1)
+        if n < 0:
+            self._check(n)
+
     def selfplay_stats(self):
         fsum = np.empty((self.n_trees,), np.float64)
         fcnt = np.empty((self.n_trees,), np.int32)
@@ -364,7 +414,7 @@ def _selfplay_methods():
         self._check(self._f["selfplay_stats"](self._h, _ptr(fsum, C.c_double), _ptr(fcnt, C.c_int32), _ptr(state, C.c_double)))
         return fsum, fcnt, state
 
-    for fn in (selfplay_begin, selfplay_step, selfplay_rows, selfplay_stats):
+    for fn in (selfplay_begin, selfplay_ring, selfplay_rows_device, selfplay_step, selfplay_rows, selfplay_clear, selfplay_stats):
         setattr(Engine, fn.__name__, fn)
 
 

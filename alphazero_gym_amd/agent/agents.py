@@ -39,7 +39,25 @@ class Agent(ABC):
     def act(self, Env): ...
 
     @abstractmethod
-    def update(self, obs: Obs) -> Dict[str, float]: ...
+    def _loss(self, states, actions, counts, values) -> Dict[str, Any]:
+        """Loss dictionary of one minibatch already on ``self.device`` (float32 tensors; values is [n, 1])."""
+
+    def _tensor(self, x):
+        """A batch field on the training device as float32: numpy arrays from ReplayBuffer, or tensors that already live on
+        the GPU (DeviceReplay minibatches: no host round trip)."""
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+        return t.to(self.device, dtype=torch.float32, non_blocking=True)
+
+    def update(self, obs: Obs) -> Dict[str, float]:
+        """One optimiser step on a minibatch (states, actions, counts, Qs, V_target) (agents.py:319-392, 539-603)."""
+        states, actions, counts, _, v_target = obs
+        self.optimizer.zero_grad(set_to_none=True)
+        loss_dict = self._loss(self._tensor(states), self._tensor(actions), self._tensor(counts), self._tensor(v_target).reshape(-1, 1))
+        loss_dict["loss"].backward()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.nn.parameters(), self.clip)
+        self.optimizer.step()
+        return {key: float(value.detach()) if hasattr(value, "detach") else float(value) for key, value in loss_dict.items()}
 
     @property
     def action_dim(self) -> int:
@@ -90,13 +108,6 @@ class Agent(ABC):
                     running_loss[key] += val
         return running_loss
 
-    def _step(self, loss_dict) -> Dict[str, float]:
-        loss_dict["loss"].backward()
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.nn.parameters(), self.clip)
-        self.optimizer.step()
-        return {key: float(value.detach()) if hasattr(value, "detach") else float(value) for key, value in loss_dict.items()}
-
 
 class DiscreteAgent(Agent):
     """agents.py:187-392"""
@@ -120,24 +131,14 @@ class DiscreteAgent(Agent):
     def mcts_forward(self, action: int, node: np.ndarray) -> None:
         self.mcts.forward(action, node)
 
-    def update(self, obs: Obs) -> Dict[str, float]:
-        """agents.py:319-392"""
-        for param in self.nn.parameters():
-            param.grad = None
-        states, actions, counts, _, V_target = obs
-        states_t = torch.from_numpy(states).float().to(self.device)
-        values_t = torch.from_numpy(V_target).unsqueeze(dim=1).float().to(self.device)
+    def _loss(self, states, actions, counts, values):
         if isinstance(self.loss, A0CLoss):
-            actions_t = torch.from_numpy(actions).float().to(self.device)
-            counts += 1   # in place, like the reference (agents.py:364): keeps log(counts) finite
-            counts_t = torch.from_numpy(counts).float().to(self.device)
-            log_probs, entropy, V_hat = self.nn.get_train_data(states_t, actions_t)
-            loss_dict = self.loss(log_probs=log_probs, counts=counts_t, entropy=entropy, V=values_t, V_hat=V_hat)
-        else:
-            probs_t = F.softmax(torch.from_numpy(counts).float(), dim=-1).to(self.device)
-            dist, V_hat = self.nn(states_t)
-            loss_dict = self.loss(dist.logits, probs_t, V_hat, values_t)
-        return self._step(loss_dict)
+            # the A0C losses on a discrete policy; counts + 1 keeps log(counts) finite (agents.py:364)
+            log_probs, entropy, V_hat = self.nn.get_train_data(states, actions)
+            return self.loss(log_probs=log_probs, counts=counts + 1, entropy=entropy, V=values, V_hat=V_hat)
+        # AlphaZero loss: cross-entropy against softmax(counts) (agents.py:378-380)
+        dist, V_hat = self.nn(states)
+        return self.loss(dist.logits, F.softmax(counts, dim=-1), V_hat, values)
 
 
 class ContinuousAgent(Agent):
@@ -172,15 +173,6 @@ class ContinuousAgent(Agent):
             action = self.epsilon_greedy(actions=actions1, values=values)
         return action, state, actions, counts, Qs, V
 
-    def update(self, obs: Obs) -> Dict[str, float]:
-        """agents.py:539-603"""
-        for param in self.nn.parameters():
-            param.grad = None
-        states, actions, counts, _, V_target = obs
-        actions_t = torch.from_numpy(actions).float().to(self.device)
-        states_t = torch.from_numpy(states).float().to(self.device)
-        counts_t = torch.from_numpy(counts).float().to(self.device)
-        values_t = torch.from_numpy(V_target).unsqueeze(dim=1).float().to(self.device)
-        log_probs, entropy, V_hat = self.nn.get_train_data(states_t, actions_t)
-        loss_dict = self.loss(log_probs=log_probs, counts=counts_t, entropy=entropy, V=values_t, V_hat=V_hat)
-        return self._step(loss_dict)
+    def _loss(self, states, actions, counts, values):
+        log_probs, entropy, V_hat = self.nn.get_train_data(states, actions)
+        return self.loss(log_probs=log_probs, counts=counts, entropy=entropy, V=values, V_hat=V_hat)

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(RK_THREADS) void results_kernel(KParams P, int Kmax
 // episode bookkeeping and the next search's root (the CPU oracle restates the same arithmetic for the parity tests).
 struct SelfPlay {
     int max_len, deterministic;
+    int final_selection;      // AZG_FS_*
+    double agent_eps;         // ContinuousAgent.epsilon
+    const double* ctab;       // c^temperature for c = 0..n_sims (NULL: temperature 1)
     unsigned step_idx;
     int* t; int* episode; int* fcnt;
     double* ret; double* fsum;
@@ -142,17 +145,52 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
         for (int a = 0; a < nc; ++a)
             for (int b = 0; b < nc; ++b) onp += ((double)rv.rec(b).edge_n / (double)tot) * rv.rec(a).Q;
     row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
-    int pick = amax;
-    if (!cont && !sp.deterministic) {
-        azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
-        double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+    int pick = 0;
+    if (cont) {
+        // ContinuousAgent.act (agents.py:524-535): actions[Qs.argmax()] / actions[counts.argmax()], first index on ties
+        pick = amax;
+        if (sp.final_selection == AZG_FS_MAX_VALUE) {
+            double qb = 0.0;
+            for (int a = 0; a < nc; ++a) { const double q = rv.rec(a).Q; if (a == 0 || q > qb) { qb = q; pick = a; } }
+        }
+        if (sp.agent_eps != 0.0) {
+            // epsilon_greedy (agents.py:471-490): random.random() < epsilon -> np.random.choice(actions)
+            azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+            if ((double)azg_u01(b.v[0]) < sp.agent_eps) pick = (int)(b.v[1] % (unsigned)nc);
+        }
+    } else {
+        // DiscreteAgent.act (agents.py:294-301): pi = stable_normalizer(Qs | counts, temperature) (helpers.py:26-27), then
+        // pi.argmax() or np.random.choice(len(pi), p=pi) (cdf = cumsum(pi); cdf /= cdf[-1]; first index with u < cdf)
+        double x[RK_MAX];
         double sum = 0.0;
-        for (int a = 0; a < nc; ++a) sum = sum + (double)rv.rec(a).edge_n / (double)cmax;
-        double cum = 0.0;
-        pick = nc - 1;
-        for (int a = 0; a < nc; ++a) {
-            cum = cum + ((double)rv.rec(a).edge_n / (double)cmax) / sum;
-            if (u < cum) { pick = a; break; }
+        for (int a = 0; a < RK_MAX; ++a) {
+            x[a] = 0.0;
+            if (a < nc) {
+                const RecL h = rv.rec(a);
+                if (sp.final_selection == AZG_FS_MAX_VALUE) x[a] = h.Q / qmax;
+                else x[a] = sp.ctab ? sp.ctab[h.edge_n] / sp.ctab[cmax] : (double)h.edge_n / (double)cmax;
+                sum = sum + x[a];
+            }
+        }
+        double best = 0.0, cum = 0.0;
+        for (int a = 0; a < RK_MAX; ++a)
+            if (a < nc) {
+                x[a] = __builtin_fabs(x[a] / sum);
+                if (a == 0 || x[a] > best) { best = x[a]; pick = a; }
+                cum = cum + x[a];
+            }
+        if (!sp.deterministic) {
+            azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+            const double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+            const double last = cum;
+            double c = 0.0;
+            pick = nc - 1;
+            bool found = false;
+            for (int a = 0; a < RK_MAX; ++a)
+                if (a < nc && !found) {
+                    c = c + x[a];
+                    if (u < c / last) { pick = a; found = true; }
+                }
         }
     }
     double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;

@@ -617,18 +617,36 @@ int azg_synthetic_roots(azg_engine* e, double* roots) {
 
 int azg_selfplay_row_len(const azg_engine* e) { return e ? e->S_obs + 3 * e->Kmax + 1 : AZG_E_INVALID; }
 
-int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
-    if (!e || max_episode_length < 1 || capacity_steps < 1) return AZG_E_INVALID;
+int azg_selfplay_begin_ex(azg_engine* e, const azg_selfplay_config* c) {
+    if (!e || !c) return AZG_E_INVALID;
+    if (c->struct_size != (int32_t)sizeof(azg_selfplay_config)) return fail(e, AZG_E_INVALID, "azg_selfplay_config size mismatch");
+    if (c->max_episode_length < 1 || c->capacity_steps < 1) return fail(e, AZG_E_INVALID, "max_episode_length and capacity_steps must be >= 1");
+    if (c->final_selection != AZG_FS_MAX_VISIT && c->final_selection != AZG_FS_MAX_VALUE) return fail(e, AZG_E_INVALID, "unknown final_selection");
+    if (c->ring_mode != AZG_RING_STOP && c->ring_mode != AZG_RING_FIFO) return fail(e, AZG_E_INVALID, "unknown ring_mode");
+    if (!(c->temperature > 0.0)) return fail(e, AZG_E_INVALID, "temperature must be > 0");
+    if (c->agent_epsilon < 0.0 || c->agent_epsilon > 1.0) return fail(e, AZG_E_INVALID, "agent_epsilon must be in [0, 1]");
+    const bool discrete = e->cfg.mode == AZG_MODE_DISCRETE;
+    if (discrete && c->final_selection == AZG_FS_MAX_VALUE && c->temperature != 1.0)
+        return fail(e, AZG_E_UNSUPPORTED, "final_selection max_value on the device supports temperature 1 only");
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (void* p : e->sp_allocs) (void)hipFree(p);
     e->sp_allocs.clear();
+    e->sp_on = 0;
     const size_t B = e->cfg.n_trees;
     e->sp_row = e->S_obs + 3 * e->Kmax + 1;
     if (dalloc(e, &e->d_sp_t, B, e->sp_allocs) || dalloc(e, &e->d_sp_episode, B, e->sp_allocs) || dalloc(e, &e->d_sp_fcnt, B, e->sp_allocs) ||
         dalloc(e, &e->d_sp_ret, B, e->sp_allocs) || dalloc(e, &e->d_sp_fsum, B, e->sp_allocs) ||
-        dalloc(e, &e->d_sp_rows, (size_t)capacity_steps * B * e->sp_row, e->sp_allocs))
+        dalloc(e, &e->d_sp_rows, (size_t)c->capacity_steps * B * e->sp_row, e->sp_allocs))
         return AZG_E_DEVICE;
+    e->d_sp_ctab = nullptr;
+    if (discrete && c->temperature != 1.0) {
+        // c^temperature for every count a root edge can reach (python float pow = libm pow, like check_pw's table)
+        std::vector<double> tab((size_t)e->cfg.n_sims + 1);
+        for (size_t i = 0; i < tab.size(); ++i) tab[i] = std::pow((double)i, c->temperature);
+        if (dalloc(e, &e->d_sp_ctab, tab.size(), e->sp_allocs)) return AZG_E_DEVICE;
+        HIPCHK(e, hipMemcpy(e->d_sp_ctab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    }
     HIPCHK(e, hipMemset(e->d_sp_t, 0, B * 4));
     HIPCHK(e, hipMemset(e->d_sp_episode, 0, B * 4));
     HIPCHK(e, hipMemset(e->d_sp_fcnt, 0, B * 4));
@@ -638,26 +656,43 @@ int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t determ
     azg_synthetic_roots(e, roots.data());
     HIPCHK(e, hipMemcpy(e->d_roots, roots.data(), roots.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemset(e->d_carry, 0, B * 4));
-    e->sp_on = 1; e->sp_max_len = max_episode_length; e->sp_det = deterministic; e->sp_cap = capacity_steps; e->sp_steps = 0;
+    e->carry_max = discrete ? e->cfg.n_sims : 0;   // a reused root carries its node count as a child: at most n_sims
+    e->sp_on = 1; e->sp_max_len = c->max_episode_length; e->sp_det = c->deterministic; e->sp_cap = c->capacity_steps; e->sp_steps = 0;
+    e->sp_insert = 0; e->sp_total = 0; e->sp_fs = c->final_selection; e->sp_ring = c->ring_mode; e->sp_agent_eps = c->agent_epsilon;
     e->sp_step_idx = 0;
     return AZG_OK;
+}
+
+int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
+    azg_selfplay_config c;
+    memset(&c, 0, sizeof(c));
+    c.struct_size = (int32_t)sizeof(c);
+    c.max_episode_length = max_episode_length; c.deterministic = deterministic; c.capacity_steps = capacity_steps;
+    c.final_selection = AZG_FS_MAX_VISIT; c.ring_mode = AZG_RING_STOP; c.temperature = 1.0; c.agent_epsilon = 0.0;
+    return azg_selfplay_begin_ex(e, &c);
 }
 
 int azg_selfplay_step(azg_engine* e) {
     if (!e) return AZG_E_INVALID;
     if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
-    if (e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
+    if (e->sp_ring == AZG_RING_STOP && e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
     int rc = azg_search_resident(e);
     if (rc) return rc;
+    ON_DEVICE(e);
+    // ReplayBuffer.store (buffers.py:75-82) for this step's block of n_trees rows
+    int slot;
+    if (e->sp_steps < e->sp_cap) { slot = e->sp_steps; e->sp_steps += 1; }
+    else { slot = e->sp_insert; e->sp_insert = (e->sp_insert + 1) % e->sp_steps; }
     SelfPlay sp;
     sp.max_len = e->sp_max_len; sp.deterministic = e->sp_det; sp.step_idx = e->sp_step_idx;
+    sp.final_selection = e->sp_fs; sp.agent_eps = e->sp_agent_eps; sp.ctab = e->d_sp_ctab;
     sp.t = e->d_sp_t; sp.episode = e->d_sp_episode; sp.fcnt = e->d_sp_fcnt; sp.ret = e->d_sp_ret; sp.fsum = e->d_sp_fsum;
-    sp.rows = e->d_sp_rows + (size_t)e->sp_steps * e->cfg.n_trees * e->sp_row;
+    sp.rows = e->d_sp_rows + (size_t)slot * e->cfg.n_trees * e->sp_row;
     sp.roots = e->d_roots; sp.carry = e->d_carry;
     const int B = e->cfg.n_trees;
     hipLaunchKernelGGL(selfplay_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
     HIPCHK(e, hipGetLastError());
-    e->sp_steps += 1;
+    e->sp_total += 1;
     e->sp_step_idx += 1;
     return AZG_OK;
 }
@@ -670,8 +705,26 @@ int azg_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear
     size_t n = (size_t)e->sp_steps * e->cfg.n_trees;
     if (n > max_rows) n = max_rows;
     if (rows && n) HIPCHK(e, hipMemcpy(rows, e->d_sp_rows, n * e->sp_row * 4, hipMemcpyDeviceToHost));
-    if (clear) e->sp_steps = 0;
+    if (clear) { e->sp_steps = 0; e->sp_insert = 0; }   // ReplayBuffer.clear (buffers.py:56-60)
     return (int)n;
+}
+
+int azg_selfplay_ring(azg_engine* e, int32_t* size_steps, int32_t* insert_step, int64_t* total_steps) {
+    if (!e) return AZG_E_INVALID;
+    if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
+    if (size_steps) *size_steps = e->sp_steps;
+    if (insert_step) *insert_step = e->sp_insert;
+    if (total_steps) *total_steps = e->sp_total;
+    return AZG_OK;
+}
+
+int azg_selfplay_rows_device(azg_engine* e, void** device_ptr, size_t* capacity_rows, size_t* row_len) {
+    if (!e || !device_ptr) return AZG_E_INVALID;
+    if (!e->sp_on) return fail(e, AZG_E_STATE, "azg_selfplay_begin has not been called");
+    *device_ptr = e->d_sp_rows;
+    if (capacity_rows) *capacity_rows = (size_t)e->sp_cap * e->cfg.n_trees;
+    if (row_len) *row_len = (size_t)e->sp_row;
+    return AZG_OK;
 }
 
 int azg_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_state) {

@@ -44,7 +44,11 @@ struct azg_engine {
     float* d_rootV; float* d_rootdist;
     double* d_roots; int* d_carry;
     uint32_t search_idx;
-    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
+    int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;   // sp_steps = ReplayBuffer.size in steps
+    int sp_insert, sp_fs, sp_ring;   // ReplayBuffer.insert_index in steps; final selection; ring mode
+    long long sp_total;              // steps played since begin
+    double sp_agent_eps;
+    double* d_sp_ctab;
     uint32_t sp_step_idx;
     int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
     std::vector<void*> sp_allocs;

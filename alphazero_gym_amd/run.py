@@ -17,7 +17,7 @@ import torch
 
 from . import _capi, distributed as D
 from .agent.agents import ContinuousAgent, DiscreteAgent
-from .agent.buffers import ReplayBuffer
+from .agent.buffers import DeviceReplay, ReplayBuffer
 from .envs import VecCartPole, VecPendulum, make_game
 from .helpers import check_space, stable_normalizer
 from .search.mcts import BatchedMCTS
@@ -187,12 +187,14 @@ class BatchedSelfPlay:
 class DeviceSelfPlay:
     """The same loop with everything but the optimiser on the GPU (azg_selfplay_* in include/azgym.h): games, final action
     rule, env step, episode resets and the replay ring live on the device; the host only downloads rows to train on.
-    The discrete final action is sampled with temperature 1.0 (the reference's default, config/agent/DiscreteAgent.yaml:11) or
-    taken greedily (``deterministic``); other temperatures: BatchedSelfPlay."""
+    The agents' final action rules run on the device too: ``final_selection`` "max_visit" / "max_value", discrete
+    ``temperature`` and ``deterministic``, continuous ``agent_epsilon`` (agents.py:294-301, 524-535; include/azgym.h).
+    ``fifo=True`` turns the replay ring into the reference's overwrite-the-oldest buffer (buffers.py:75-82)."""
 
     def __init__(self, policy, *, game: str, n_games: int, n_rollouts: int, c_uct: float, gamma: float = 1.0, epsilon: float = 0.0,
                  c_pw: float = 1.0, kappa: float = 0.5, V_target_policy: str = "off_policy", max_episode_length: int = 200,
-                 deterministic: bool = False, capacity_steps: int = 64, seed: int = 34, rank: int = 0, device_id: int = 0):
+                 deterministic: bool = False, capacity_steps: int = 64, seed: int = 34, rank: int = 0, device_id: int = 0,
+                 final_selection: str = "max_visit", temperature: float = 1.0, agent_epsilon: float = 0.0, fifo: bool = False):
         self.continuous = game.lower().startswith("pendulum")
         if self.continuous:
             env_id = _capi.ENV_PENDULUM_V0 if game.endswith("v0") else _capi.ENV_PENDULUM_V1
@@ -205,15 +207,48 @@ class DeviceSelfPlay:
                                     V_target_policy=V_target_policy, seed=seed, tree_id_base=rank * n_games, device_id=device_id)
         self.engine = self.mcts.engine
         self.capacity = capacity_steps
-        self.engine.selfplay_begin(max_episode_length, deterministic, capacity_steps)
+        self.fifo = fifo
+        self.engine.selfplay_begin(max_episode_length, deterministic, capacity_steps, final_selection=final_selection,
+                                   temperature=temperature, agent_epsilon=agent_epsilon, fifo=fifo)
 
-    def collect(self, n_steps: int) -> torch.Tensor:
-        """Play n_steps (<= capacity) and return this rank's replay rows as float32 [n_steps * B, row]."""
-        assert n_steps <= self.capacity
+    def play(self, n_steps: int) -> None:
+        """n_steps self-play steps of every game (asynchronous: launches only); rows accumulate in the device ring."""
+        assert self.fifo or n_steps <= self.capacity
         self.mcts.sync_weights()
         for _ in range(n_steps):
             self.engine.selfplay_step()
+
+    def collect(self, n_steps: int) -> torch.Tensor:
+        """Play n_steps (<= capacity) and return this rank's replay rows as a host float32 tensor [n_steps * B, row]."""
+        assert n_steps <= self.capacity
+        self.play(n_steps)
         return torch.from_numpy(self.engine.selfplay_rows(clear=True).copy())
+
+    def replay(self, batch_size: int, device=None) -> DeviceReplay:
+        """The device ring as a replay buffer with the reference's sampling rules; minibatches are device tensors."""
+        return DeviceReplay(self.engine, batch_size, device=device)
+
+    def collect_device(self, n_steps: int, replay: DeviceReplay) -> torch.Tensor:
+        """Play n_steps and return this rank's NEW rows as a device tensor [n_steps * B, row] (a copy in HBM; the ring is
+        cleared unless it runs in FIFO mode, where it keeps accumulating)."""
+        if not self.fifo:
+            assert n_steps <= self.capacity
+            self.play(n_steps)
+            rows = replay.rows().clone()
+            self.engine.selfplay_clear()
+            return rows
+        before = self.engine.selfplay_ring()
+        self.play(n_steps)
+        size, insert, _ = self.engine.selfplay_ring()
+        B = self.engine.n_trees
+        ring = replay.rows().reshape(size, B, -1)
+        # the n_steps newest slots, oldest first: while filling they are the tail; once full they end just before insert_index
+        if before[0] + n_steps <= self.capacity:
+            new = ring[before[0]:before[0] + n_steps]
+        else:
+            idx = [(insert - n_steps + i) % size for i in range(n_steps)]
+            new = ring[torch.as_tensor(idx, device=ring.device)]
+        return new.reshape(n_steps * B, -1).clone()
 
     def mean_finished_return(self) -> float:
         fsum, fcnt, _ = self.engine.selfplay_stats()
@@ -223,7 +258,12 @@ class DeviceSelfPlay:
 def train_on_rows(agent, rows: torch.Tensor, state_dim: int, K: int, batch_size: int = 32, shuffle_seed: int = 0) -> Dict[str, float]:
     """One epoch of minibatch updates (agent.update) over replay rows gathered from all ranks; the last batch absorbs the
     remainder like ReplayBuffer.__next__."""
-    s, a, c, q, v = D.unpack_replay_rows(rows, state_dim, K)
+    on_device = rows.is_cuda
+    if on_device:   # minibatches are gathered on the GPU, nothing goes through the host
+        s, a, c, q, v = (rows[:, :state_dim], rows[:, state_dim:state_dim + K], rows[:, state_dim + K:state_dim + 2 * K],
+                         rows[:, state_dim + 2 * K:state_dim + 3 * K], rows[:, -1])
+    else:
+        s, a, c, q, v = D.unpack_replay_rows(rows, state_dim, K)
     n = s.shape[0]
     order = np.random.RandomState(shuffle_seed).permutation(n)
     sums: Dict[str, float] = {}
@@ -231,7 +271,11 @@ def train_on_rows(agent, rows: torch.Tensor, state_dim: int, K: int, batch_size:
     while i < n:
         j = n if i + 2 * batch_size > n else i + batch_size
         idx = order[i:j]
-        info = agent.update((s[idx].copy(), a[idx].copy(), c[idx].copy(), q[idx].copy(), v[idx].astype(np.float64)))
+        if on_device:
+            ti = torch.from_numpy(idx).to(rows.device)
+            info = agent.update((s[ti], a[ti], c[ti], q[ti], v[ti]))
+        else:
+            info = agent.update((s[idx].copy(), a[idx].copy(), c[idx].copy(), q[idx].copy(), v[idx].astype(np.float64)))
         for k_, val in info.items():
             sums[k_] = sums.get(k_, 0.0) + val
         i = j

@@ -75,15 +75,18 @@ def train(a, log=print):
     fs0, fc0 = 0.0, 0
     t0 = time.time()
     history = []
+    # with the policy on the GPU the replay rows never leave HBM: the ring is wrapped as a torch tensor (zero copy), the
+    # all-gather runs device to device over xGMI, and the minibatches are gathered on the GPU
+    on_gpu = a.device.startswith("cuda")
+    replay = sp.replay(a.batch_size) if on_gpu else None
     for it in range(a.iters):
-        rows = sp.collect(a.steps_per_iter)
+        rows = sp.collect_device(a.steps_per_iter, replay) if on_gpu else sp.collect(a.steps_per_iter)
         if world > 1:
-            rows = D.gather_replay_rows(rows, device=a.device if a.device.startswith("cuda") else None)   # every rank's games
-            rows = rows.cpu()
+            rows = D.gather_replay_rows(rows)   # every rank's games
         info = {"loss": 0.0}
         pick = rng.choice(rows.shape[0], size=min(a.train_rows, rows.shape[0]), replace=False)
         if rank == 0:
-            info = run.train_on_rows(agent, rows[torch.from_numpy(pick)], state_dim, K, batch_size=a.batch_size, shuffle_seed=it)
+            info = run.train_on_rows(agent, rows[torch.from_numpy(pick).to(rows.device)], state_dim, K, batch_size=a.batch_size, shuffle_seed=it)
         if world > 1:
             D.broadcast_weights(agent.nn, src=0)
         fsum, fcnt, _ = sp.engine.selfplay_stats()

@@ -154,6 +154,37 @@ int azg_sync(azg_engine* e);
  * step, episode bookkeeping (reset on termination or after max_episode_length steps) and the next search's root
  * (discrete: with the reused root's carried visit count, MCTSDiscrete.forward mcts.py:495-526). */
 int azg_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps);
+
+/* The agents' whole final-action surface and the replay buffer's overwrite rule:
+ *   final_selection  "max_visit(s)" / "max_value" (agents.py:294-301, 524-535): the rule works on the root's counts or its Qs
+ *   discrete   pi = stable_normalizer(x, temperature) = |y / sum(y)|, y = (x / max(x))^temperature (helpers.py:9-27);
+ *              action = pi.argmax() (deterministic) or sampled from pi by inverse CDF as numpy's choice() does
+ *              (cdf = cumsum(pi) / cdf[-1], first index with u < cdf) with u from the engine's Philox stream.
+ *              Counts: any temperature (c^t from a host-built libm table, (c / max)^t = c^t / max^t); Qs: temperature 1 only.
+ *   continuous actions[x.argmax()] (first index on ties), or with probability agent_epsilon a uniformly random root action
+ *              (ContinuousAgent.epsilon_greedy, agents.py:471-490)
+ *   ring_mode  AZG_RING_STOP: azg_selfplay_step fails once capacity_steps steps are stored (download and clear);
+ *              AZG_RING_FIFO: ReplayBuffer.store (buffers.py:75-82) in units of one step (n_trees rows): append until full,
+ *              then overwrite slot insert_index and advance it cyclically. */
+enum { AZG_FS_MAX_VISIT = 0, AZG_FS_MAX_VALUE = 1 };
+enum { AZG_RING_STOP = 0, AZG_RING_FIFO = 1 };
+typedef struct azg_selfplay_config {
+    int32_t struct_size;        /* sizeof(azg_selfplay_config), checked */
+    int32_t max_episode_length; /* cfg.max_episode_length (run_*.py) */
+    int32_t deterministic;      /* DiscreteAgent.act(deterministic=...) */
+    int32_t capacity_steps;     /* replay ring capacity in steps: ReplayBuffer.max_size = capacity_steps * n_trees rows */
+    int32_t final_selection;    /* AZG_FS_* */
+    int32_t ring_mode;          /* AZG_RING_* */
+    double temperature;         /* DiscreteAgent.temperature */
+    double agent_epsilon;       /* ContinuousAgent.epsilon */
+} azg_selfplay_config;
+int azg_selfplay_begin_ex(azg_engine* e, const azg_selfplay_config* cfg);
+/* ReplayBuffer.size and .insert_index in steps, and the number of steps played since begin */
+int azg_selfplay_ring(azg_engine* e, int32_t* size_steps, int32_t* insert_step, int64_t* total_steps);
+/* the ring itself, for consumers on the same device (training batches gathered and all-gathered HBM -> HBM, no PCIe hop):
+ * device pointer to [capacity_steps][n_trees][row_len] float32, valid until the next azg_selfplay_begin* / destroy; rows of the
+ * first size_steps slots are defined once the engine's stream is synchronised (azg_sync). */
+int azg_selfplay_rows_device(azg_engine* e, void** device_ptr, size_t* capacity_rows, size_t* row_len);
 int azg_selfplay_step(azg_engine* e);
 int azg_selfplay_row_len(const azg_engine* e);
 /* rows of the steps played since the last clear, ordered [step][tree]; returns the number of rows copied */

@@ -86,6 +86,9 @@ struct azg_engine {
     int searched;
     /* self-play */
     int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
+    int sp_insert, sp_fs, sp_ring;
+    long long sp_total;
+    double sp_temperature, sp_agent_eps;
     uint32_t sp_step_idx;
     int32_t* sp_t; int32_t* sp_episode; int32_t* sp_fcnt; double* sp_ret; double* sp_fsum; float* sp_rows;
     char err[256];
@@ -721,15 +724,25 @@ int azo_synthetic_roots(azg_engine* e, double* roots) {
 
 int azo_selfplay_row_len(const azg_engine* e) { return e ? e->S_obs + 3 * e->Kmax + 1 : AZG_E_INVALID; }
 
-int azo_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
-    if (!e || max_episode_length < 1 || capacity_steps < 1) return AZG_E_INVALID;
+int azo_selfplay_begin_ex(azg_engine* e, const azg_selfplay_config* c) {
+    if (!e || !c) return AZG_E_INVALID;
+    if (c->struct_size != (int32_t)sizeof(azg_selfplay_config)) return fail(e, AZG_E_INVALID, "azg_selfplay_config size mismatch");
+    if (c->max_episode_length < 1 || c->capacity_steps < 1) return fail(e, AZG_E_INVALID, "max_episode_length and capacity_steps must be >= 1");
+    if (c->final_selection != AZG_FS_MAX_VISIT && c->final_selection != AZG_FS_MAX_VALUE) return fail(e, AZG_E_INVALID, "unknown final_selection");
+    if (c->ring_mode != AZG_RING_STOP && c->ring_mode != AZG_RING_FIFO) return fail(e, AZG_E_INVALID, "unknown ring_mode");
+    if (!(c->temperature > 0.0)) return fail(e, AZG_E_INVALID, "temperature must be > 0");
+    if (c->agent_epsilon < 0.0 || c->agent_epsilon > 1.0) return fail(e, AZG_E_INVALID, "agent_epsilon must be in [0, 1]");
+    if (e->cfg.mode == AZG_MODE_DISCRETE && c->final_selection == AZG_FS_MAX_VALUE && c->temperature != 1.0)
+        return fail(e, AZG_E_UNSUPPORTED, "final_selection max_value on the device supports temperature 1 only");
     int B = e->cfg.n_trees;
     free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
     e->sp_row = e->S_obs + 3 * e->Kmax + 1;
     e->sp_t = (int32_t*)calloc(B, 4); e->sp_episode = (int32_t*)calloc(B, 4); e->sp_fcnt = (int32_t*)calloc(B, 4);
     e->sp_ret = (double*)calloc(B, 8); e->sp_fsum = (double*)calloc(B, 8);
-    e->sp_rows = (float*)calloc((size_t)capacity_steps * B * e->sp_row, 4);
-    e->sp_on = 1; e->sp_max_len = max_episode_length; e->sp_det = deterministic; e->sp_cap = capacity_steps; e->sp_steps = 0;
+    e->sp_rows = (float*)calloc((size_t)c->capacity_steps * B * e->sp_row, 4);
+    e->sp_on = 1; e->sp_max_len = c->max_episode_length; e->sp_det = c->deterministic; e->sp_cap = c->capacity_steps; e->sp_steps = 0;
+    e->sp_insert = 0; e->sp_total = 0; e->sp_fs = c->final_selection; e->sp_ring = c->ring_mode;
+    e->sp_temperature = c->temperature; e->sp_agent_eps = c->agent_epsilon;
     e->sp_step_idx = 0;
     for (int i = 0; i < B; ++i)
         azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, e->roots + (size_t)i * e->S_env);
@@ -737,25 +750,40 @@ int azo_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t determ
     return AZG_OK;
 }
 
+int azo_selfplay_begin(azg_engine* e, int32_t max_episode_length, int32_t deterministic, int32_t capacity_steps) {
+    azg_selfplay_config c;
+    memset(&c, 0, sizeof(c));
+    c.struct_size = (int32_t)sizeof(c);
+    c.max_episode_length = max_episode_length; c.deterministic = deterministic; c.capacity_steps = capacity_steps;
+    c.final_selection = AZG_FS_MAX_VISIT; c.ring_mode = AZG_RING_STOP; c.temperature = 1.0; c.agent_epsilon = 0.0;
+    return azo_selfplay_begin_ex(e, &c);
+}
+
+/* One step of the run loops (run_continuous.py:111-142, run_discrete.py:94-122) for every game: act (search + final action,
+ * agents.py:257-303, 492-537), buffer.store, Env.step, then reset_mcts / mcts_forward or the episode's end. */
 int azo_selfplay_step(azg_engine* e) {
     if (!e || !e->sp_on) return e ? fail(e, AZG_E_STATE, "azo_selfplay_begin has not been called") : AZG_E_INVALID;
-    if (e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
+    if (e->sp_ring == AZG_RING_STOP && e->sp_steps >= e->sp_cap) return fail(e, AZG_E_STATE, "replay ring is full: download and clear the rows");
     int rc = azo_search_resident(e);
     if (rc) return rc;
     const int B = e->cfg.n_trees, K = e->Kmax, S = e->S_env, So = e->S_obs, RL = e->sp_row;
     const int cont = e->cfg.mode == AZG_MODE_CONTINUOUS;
-    float* rows = e->sp_rows + (size_t)e->sp_steps * B * RL;
+    /* ReplayBuffer.store (buffers.py:75-82), one step block of B rows at a time */
+    int slot;
+    if (e->sp_steps < e->sp_cap) { slot = e->sp_steps; e->sp_steps += 1; }
+    else { slot = e->sp_insert; e->sp_insert += 1; if (e->sp_insert >= e->sp_steps) e->sp_insert = 0; }
+    float* rows = e->sp_rows + (size_t)slot * B * RL;
     for (int i = 0; i < B; ++i) {
         tree_t* t = &e->trees[i];
         const uint32_t gtree = (uint32_t)(e->cfg.tree_id_base + i);
         double* root = e->roots + (size_t)i * S;
         float* row = rows + (size_t)i * RL;
         int nc = t->n_child[0];
-        /* replay row */
+        /* replay row (s, actions, counts, Qs, V) of buffer.store */
         env_obs(e->cfg.env_id, root, row);
         double qmax = 0.0, onp = 0.0;
         long tot = 0;
-        int cmax = 0, amax = 0;
+        int cmax = 0, amax = 0, qarg = 0;
         for (int a = 0; a < nc; ++a) tot += t->edge_n[t->child[a]];
         for (int a = 0; a < K; ++a) {
             int k = a < nc ? t->child[a] : -1;
@@ -763,28 +791,55 @@ int azo_selfplay_step(azg_engine* e) {
             row[So + K + a] = k >= 0 ? (float)t->edge_n[k] : 0.0f;
             row[So + 2 * K + a] = k >= 0 ? (float)t->edge_Q[k] : 0.0f;
             if (k >= 0) {
-                if (a == 0 || t->edge_Q[k] > qmax) qmax = t->edge_Q[k];
+                if (a == 0 || t->edge_Q[k] > qmax) { qmax = t->edge_Q[k]; qarg = a; }   /* first index on ties */
                 if (!cont) onp += ((double)t->edge_n[k] / (double)tot) * t->edge_Q[k];
-                if (a == 0 || t->edge_n[k] > cmax) { cmax = t->edge_n[k]; amax = a; }   /* first index on ties */
+                if (a == 0 || t->edge_n[k] > cmax) { cmax = t->edge_n[k]; amax = a; }
             }
         }
         if (cont)
             for (int a = 0; a < nc; ++a)
                 for (int b = 0; b < nc; ++b) onp += ((double)t->edge_n[t->child[b]] / (double)tot) * t->edge_Q[t->child[a]];
         row[So + 3 * K] = (float)(e->cfg.v_target == AZG_VT_ON_POLICY ? onp : qmax);
-        /* final action (agents.py:294-301, 524-535) */
-        int pick = amax;
-        if (!cont && !e->sp_det) {
-            azg_u32x4 b = azg_draw(e->cfg.seed, gtree, e->sp_step_idx, 0u, AZG_STREAM_ACT);
-            double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
-            /* stable_normalizer(counts, 1.0) (helpers.py:26-27): x = c/max; pi = x/sum(x); inverse-CDF with u */
-            double sum = 0.0;
-            for (int a = 0; a < nc; ++a) sum = sum + (double)t->edge_n[t->child[a]] / (double)cmax;
-            double cum = 0.0;
-            pick = nc - 1;
+        /* final action */
+        int pick;
+        if (cont) {
+            /* ContinuousAgent.act (agents.py:524-535) */
+            pick = e->sp_fs == AZG_FS_MAX_VALUE ? qarg : amax;
+            if (e->sp_agent_eps != 0.0) {
+                /* epsilon_greedy (agents.py:471-490) */
+                azg_u32x4 b = azg_draw(e->cfg.seed, gtree, e->sp_step_idx, 0u, AZG_STREAM_ACT);
+                if ((double)azg_u01(b.v[0]) < e->sp_agent_eps) pick = (int)(b.v[1] % (uint32_t)nc);
+            }
+        } else {
+            /* DiscreteAgent.act (agents.py:294-301) with stable_normalizer (helpers.py:26-27): y = (x / max x) ** temp,
+             * pi = |y / sum(y)|; then pi.argmax() or numpy's choice(len(pi), p=pi): cdf = cumsum(pi); cdf /= cdf[-1];
+             * index = searchsorted(cdf, u, side="right") */
+            double pi[64], sum = 0.0;
             for (int a = 0; a < nc; ++a) {
-                cum = cum + ((double)t->edge_n[t->child[a]] / (double)cmax) / sum;
-                if (u < cum) { pick = a; break; }
+                int k = t->child[a];
+                double y;
+                if (e->sp_fs == AZG_FS_MAX_VALUE) y = t->edge_Q[k] / qmax;   /* temperature 1 */
+                else if (e->sp_temperature == 1.0) y = (double)t->edge_n[k] / (double)cmax;
+                else y = pow((double)t->edge_n[k], e->sp_temperature) / pow((double)cmax, e->sp_temperature);   /* = (c/max)^t */
+                pi[a] = y;
+                sum = sum + y;
+            }
+            double best = 0.0, last = 0.0;
+            pick = 0;
+            for (int a = 0; a < nc; ++a) {
+                pi[a] = fabs(pi[a] / sum);
+                if (a == 0 || pi[a] > best) { best = pi[a]; pick = a; }
+                last = last + pi[a];
+            }
+            if (!e->sp_det) {
+                azg_u32x4 b = azg_draw(e->cfg.seed, gtree, e->sp_step_idx, 0u, AZG_STREAM_ACT);
+                double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+                double cum = 0.0;
+                pick = nc - 1;
+                for (int a = 0; a < nc; ++a) {
+                    cum = cum + pi[a];
+                    if (u < cum / last) { pick = a; break; }
+                }
             }
         }
         int krec = t->child[pick];
@@ -809,7 +864,7 @@ int azo_selfplay_step(azg_engine* e) {
             e->carry[i] = (!cont && (t->flags[krec] & FLAG_EXPANDED)) ? t->node_n[krec] : 0;
         }
     }
-    e->sp_steps += 1;
+    e->sp_total += 1;
     e->sp_step_idx += 1;
     return AZG_OK;
 }
@@ -819,8 +874,25 @@ int azo_selfplay_rows(azg_engine* e, float* rows, size_t max_rows, int32_t clear
     size_t n = (size_t)e->sp_steps * e->cfg.n_trees;
     if (n > max_rows) n = max_rows;
     if (rows) memcpy(rows, e->sp_rows, n * e->sp_row * 4);
-    if (clear) e->sp_steps = 0;
+    if (clear) { e->sp_steps = 0; e->sp_insert = 0; }
     return (int)n;
+}
+
+int azo_selfplay_ring(azg_engine* e, int32_t* size_steps, int32_t* insert_step, int64_t* total_steps) {
+    if (!e || !e->sp_on) return AZG_E_STATE;
+    if (size_steps) *size_steps = e->sp_steps;
+    if (insert_step) *insert_step = e->sp_insert;
+    if (total_steps) *total_steps = e->sp_total;
+    return AZG_OK;
+}
+
+/* (host memory here: the oracle has no device) */
+int azo_selfplay_rows_device(azg_engine* e, void** ptr, size_t* capacity_rows, size_t* row_len) {
+    if (!e || !ptr || !e->sp_on) return AZG_E_STATE;
+    *ptr = e->sp_rows;
+    if (capacity_rows) *capacity_rows = (size_t)e->sp_cap * e->cfg.n_trees;
+    if (row_len) *row_len = (size_t)e->sp_row;
+    return AZG_OK;
 }
 
 int azo_selfplay_stats(azg_engine* e, double* fsum, int32_t* fcnt, double* env_state) {
@@ -864,6 +936,19 @@ void azo_eps_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, 
     azg_u32x4 b = azg_draw(seed, tree, search, draw, AZG_STREAM_EPS);
     *u = azg_u01(b.v[0]);
     *r = b.v[1];
+}
+
+/* the self-play draws: a game's reset state of an episode, and the final-action draw of a step (u01 float for
+ * `random.random() < epsilon`, the double uniform of the inverse-CDF sample, the raw word of the uniform index) */
+void azo_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s) {
+    azg_reset_state(seed, tree, episode, env_is_cartpole, s);
+}
+
+void azo_act_draw(uint64_t seed, uint32_t tree, uint32_t step, float* u01, double* u, uint32_t* word1) {
+    azg_u32x4 b = azg_draw(seed, tree, step, 0u, AZG_STREAM_ACT);
+    *u01 = azg_u01(b.v[0]);
+    *u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+    *word1 = b.v[1];
 }
 
 float azo_sample_action(float mu, float sigma, float eps, float bound) { return bound * azg_tanhf(mu + sigma * eps); }

@@ -2,6 +2,7 @@
 """Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE (build container only).
 
     python tests/golden/gen_golden.py            # needs /root/reference; writes tests/golden/*.npz
+    python tests/golden/gen_golden.py t7         # only the self-play tier
 
 The reference (timoklein/alphazero-gym) is imported unmodified from /root/reference.  `gym`, `hydra`
 and `omegaconf` are not installed in this image; the reference's hot path only needs their names for
@@ -19,6 +20,11 @@ Tiers (SURVEY.md 7 "hard parts"):
   T3  end to end.   The reference with its real torch policy, torch.normal patched to the engine's
       noise: visit counts / Q for whole searches (near-tie flips from ~1e-7 MLP differences possible).
   T4  agent.        DiscreteAgent.act / ContinuousAgent.act return tuples (shapes, dtypes, final action).
+  T5  training.     get_train_data and the losses on fixed batches.
+  T6  replay.       The reference's ReplayBuffer through wrap-around and two epochs of minibatches.
+  T7  self-play.    The reference's run loops (run_continuous.py:111-142, run_discrete.py:94-122: act -> buffer.store ->
+      Env.step -> reset_mcts | mcts_forward, episode ends and resets) driven with the reference's own agents for several
+      games over episode boundaries; pins azo_selfplay_* / azg_selfplay_* (replay rows, final actions, returns, carried roots).
 """
 import os
 import sys
@@ -617,7 +623,177 @@ def run_t6():
     return out
 
 
+T7_CASES = {
+    # Pendulum, the default rule: most visited root action; episodes end by length (Pendulum never terminates)
+    "pendulum": dict(env_id=2, mode=1, n_sims=20, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0.0, v_target="off_policy",
+                     hidden=[64, 64], act="elu", wseed=3, seed=11, tree_id_base=5, n_games=3, n_steps=9, max_len=4),
+    # final_selection max_value + the agent's epsilon-greedy, Pendulum-v0, discounting, eps-greedy inside the search too
+    "pendulum_maxvalue_eps": dict(env_id=1, mode=1, n_sims=24, c_uct=0.1, c_pw=1, kappa=0.6, gamma=0.97, epsilon=0.1,
+                                  v_target="on_policy", hidden=[64], act="relu", wseed=4, seed=12, tree_id_base=0, n_games=3,
+                                  n_steps=8, max_len=5, final_selection="max_value", agent_eps=0.4),
+    # CartPole: deterministic final action, tree reuse through mcts_forward, episodes cut by length
+    "cartpole_det": dict(env_id=0, mode=0, num_actions=2, n_sims=16, c_uct=20.0, gamma=0.97, epsilon=0.0, v_target="off_policy",
+                         hidden=[64, 64], act="relu", wseed=3, wscale=2.0, seed=13, tree_id_base=2, n_games=3, n_steps=14, max_len=6,
+                         det=True),
+    # sampled final action (temperature 1), long enough for real terminations
+    "cartpole_sampled": dict(env_id=0, mode=0, num_actions=2, n_sims=12, c_uct=30.0, gamma=0.9, epsilon=0.0, v_target="on_policy",
+                             hidden=[64, 64], act="relu", wseed=6, wscale=3.0, seed=14, tree_id_base=0, n_games=4, n_steps=60,
+                             max_len=200, det=False),
+    # sampled with temperature 0.5
+    "cartpole_temp": dict(env_id=0, mode=0, num_actions=2, n_sims=16, c_uct=5.0, gamma=0.97, epsilon=0.0, v_target="off_policy",
+                          hidden=[64], act="relu", wseed=7, wscale=2.0, seed=15, tree_id_base=1, n_games=3, n_steps=12, max_len=5,
+                          det=False, temperature=0.5),
+    # final_selection max_value, sampled from the normalised Qs (temperature 1)
+    "cartpole_maxvalue": dict(env_id=0, mode=0, num_actions=2, n_sims=16, c_uct=5.0, gamma=0.97, epsilon=0.0, v_target="off_policy",
+                              hidden=[64], act="relu", wseed=8, wscale=2.0, seed=16, tree_id_base=0, n_games=3, n_steps=10, max_len=7,
+                              det=False, final_selection="max_value"),
+}
+
+
+def run_t7(case):
+    """The reference's run loop for every game of a self-play batch (see the module docstring).  What the engine defines and
+    the reference receives through patched RNG entry points: the reset state of an episode (stands in for Env.reset()), the
+    search noise / eps-greedy draws (as in T1) and the final-action draw of a step (np.random.choice / random.random in
+    alphazero/agent/agents.py, patched to numpy's own inverse-CDF rule on the engine's uniform)."""
+    import alphazero.agent.agents as RA
+    from alphazero.agent.buffers import ReplayBuffer
+    cont = case["mode"] == 1
+    in_dim = 3 if cont else 4
+    n_dist = 2 if cont else case["num_actions"]
+    seed = case["seed"]
+    eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
+                         gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0),
+                         c_pw=case.get("c_pw", 1.0), kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=seed)
+    eng.set_weights(_capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]),
+                    O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0)))
+    K, So = eng.kmax, eng.s_obs
+    fs = case.get("final_selection", "max_visit")
+    n_steps, max_len = case["n_steps"], case["max_len"]
+    G = case["n_games"]
+    rows = np.zeros((n_steps, G, So + 3 * K + 1), np.float64)
+    act_idx = np.zeros((n_steps, G), np.int32)
+    act_val = np.zeros((n_steps, G), np.float64)
+    root_before = np.zeros((n_steps, G, eng.s_env), np.float64)
+    carry_in = np.zeros((n_steps, G), np.int32)
+    fsum, fcnt = np.zeros(G), np.zeros(G, np.int32)
+    final_state = np.zeros((G, eng.s_env))
+    step_box = {"gt": 0, "step": 0}
+
+    class ActRandom:   # `random` inside alphazero.agent.agents (epsilon_greedy, agents.py:487)
+        @staticmethod
+        def random():
+            return O.act_draw(seed, step_box["gt"], step_box["step"])[0]
+
+    def fake_choice(a, p=None, **kw):   # np.random.choice inside alphazero.agent.agents (agents.py:299, 301, 488)
+        u01, u, word = O.act_draw(seed, step_box["gt"], step_box["step"])
+        if p is None:
+            a = np.asarray(a)
+            return a[word % len(a)]
+        cdf = np.asarray(p, dtype=np.float64).cumsum()
+        cdf /= cdf[-1]
+        return int(cdf.searchsorted(u, side="right"))
+
+    orig_choice, orig_random = np.random.choice, RA.random
+    np.random.choice = fake_choice
+    RA.random = ActRandom
+    try:
+        for g in range(G):
+            gt = case["tree_id_base"] + g
+            step_box["gt"] = gt
+            if cont:
+                env = PendulumEnv(version=1 if case["env_id"] == 2 else 0)
+                ag = object.__new__(RA.ContinuousAgent)
+                ag.final_selection = fs; ag.epsilon = case.get("agent_eps", 0)
+                ag.mcts = RM.MCTSContinuous(model=None, n_rollouts=case["n_sims"], c_uct=case["c_uct"], c_pw=case["c_pw"],
+                                            kappa=case["kappa"], gamma=case["gamma"], epsilon=case["epsilon"],
+                                            V_target_policy=case["v_target"], device="cpu", root_state=None)
+            else:
+                env = CartPoleEnv()
+                ag = object.__new__(RA.DiscreteAgent)
+                ag.final_selection = fs; ag.temperature = case.get("temperature", 1.0)
+                ag.mcts = RM.MCTSDiscrete(model=None, num_actions=case["num_actions"], n_rollouts=case["n_sims"], c_uct=case["c_uct"],
+                                          gamma=case["gamma"], epsilon=case["epsilon"], V_target_policy=case["v_target"],
+                                          device="cpu", root_state=None)
+            buffer = ReplayBuffer(max_size=10 ** 6, batch_size=8)
+            step, episode = 0, 0
+            while step < n_steps:
+                # Env.reset() (run_*.py: `state = Env.reset()`), with the engine's reset state of (game, episode)
+                rs = O.reset_state(seed, gt, episode, not cont)
+                env.state = np.asarray(rs, np.float64) if cont else tuple(float(v) for v in rs)
+                state = env._get_obs() if cont else np.array(env.state, dtype=np.float32)
+                R = 0.0
+                ag.reset_mcts(root_state=state)
+                for t in range(max_len):
+                    step_box["step"] = step
+                    ag.mcts.model = OracleModel(eng, seed, gt, step, 2.0)
+                    RM.random = EngineRandom(seed, gt, step)
+                    COUNTER["n"] = 0
+                    root_before[step, g] = env.azg_state()
+                    carry_in[step, g] = 0 if ag.mcts.root_node is None else ag.mcts.root_node.n
+                    if cont:
+                        action, s, actions, counts, Qs, V = ag.act(Env=env)
+                    else:
+                        action, s, actions, counts, Qs, V = ag.act(Env=env, deterministic=case["det"])
+                    buffer.store((s, actions, counts, Qs, V))
+                    nc = len(counts)
+                    row = rows[step, g]
+                    row[:So] = np.asarray(s, np.float64).reshape(-1)
+                    row[So:So + nc] = np.asarray(actions, np.float64).reshape(-1)
+                    row[So + K:So + K + nc] = counts
+                    row[So + 2 * K:So + 2 * K + nc] = np.asarray(Qs, np.float64).reshape(-1)
+                    row[So + 3 * K] = float(np.asarray(V).reshape(-1)[0])
+                    if cont:
+                        act_val[step, g] = float(np.asarray(action).reshape(-1)[0])
+                        act_idx[step, g] = int(np.where(np.atleast_1d(actions) == action[0])[0][0])
+                    else:
+                        act_idx[step, g] = int(action)
+                        act_val[step, g] = float(action)
+                    state, step_reward, terminal, _ = env.step(action)
+                    R += float(np.asarray(step_reward).reshape(-1)[0])
+                    step += 1
+                    if terminal or t == max_len - 1:
+                        fsum[g] += R
+                        fcnt[g] += 1
+                        break
+                    if cont:
+                        ag.reset_mcts(root_state=state)       # run_continuous.py:140-142
+                    else:
+                        ag.mcts_forward(action, state)        # run_discrete.py:121-122
+                    if step >= n_steps:
+                        break
+                else:
+                    pass
+                if step >= n_steps and not (terminal or t == max_len - 1):
+                    final_state[g] = env.azg_state()          # stopped in the middle of an episode
+                    break
+                episode += 1
+                if step >= n_steps:
+                    # the device resets the game in the same step that ends the episode
+                    final_state[g] = O.reset_state(seed, gt, episode, not cont)
+            assert len(buffer) == n_steps
+            # the buffer holds what the rows hold (buffer.store is the reference's own)
+            for i, exp in enumerate(buffer.experience):
+                np.testing.assert_array_equal(np.asarray(exp[2]).reshape(-1), rows[i, g, So + K:So + K + len(exp[2])])
+    finally:
+        np.random.choice = orig_choice
+        RA.random = orig_random
+    eng.close()
+    return dict(rows=rows, act_idx=act_idx, act_val=act_val, root_before=root_before, carry_in=carry_in, fsum=fsum, fcnt=fcnt,
+                final_state=final_state, case=np.array(repr(case)))
+
+
+def main_t7():
+    for name, case in T7_CASES.items():
+        TIES["n"] = 0
+        t7 = run_t7(case)
+        assert TIES["n"] == 0, f"t7 {name}: argmax tie occurred in the reference run; pick other inputs"
+        np.savez_compressed(os.path.join(HERE, f"t7_selfplay_{name}.npz"), **t7)
+        print("t7", name, "episodes", t7["fcnt"].tolist(), "returns", np.round(t7["fsum"], 3).tolist(), "actions[:, 0]", t7["act_idx"][:, 0].tolist())
+
+
 def main():
+    if sys.argv[1:] == ["t7"]:   # only the self-play tier (the other fixtures are left untouched)
+        return main_t7()
     for name, case in T1_CASES.items():
         TIES["n"] = 0
         res = run_t1(case)
@@ -641,7 +817,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "t6_buffer.npz"), **t6)
     print("t6", t6["slots"][-1].tolist(), t6["batches"].tolist())
     print("t3 ties", TIES["n"], "c_counts[0]", t3["c_counts"][0].tolist(), "d_counts", t3["d_counts"].tolist())
-
+    main_t7()
 
 if __name__ == "__main__":
     main()

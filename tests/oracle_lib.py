@@ -48,6 +48,10 @@ def lib():
         _lib.azo_gmm_u.restype = C.c_float
         _lib.azo_sample_action.restype = C.c_float
         _lib.azo_math_eval.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
+        _lib.azo_reset_state.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+        _lib.azo_reset_state.restype = None
+        _lib.azo_act_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        _lib.azo_act_draw.restype = None
         _lib.azo_env_step.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         _lib.azo_env_obs.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
@@ -77,6 +81,20 @@ def eps_draw(seed, tree, search, draw):
     r = C.c_uint32()
     lib().azo_eps_draw(seed, tree, search, draw, C.byref(u), C.byref(r))
     return float(u.value), int(r.value)
+
+
+def reset_state(seed, tree, episode, cartpole):
+    """A self-play game's initial state of an episode (the engine's stand-in for Env.reset())."""
+    out = np.zeros(4, np.float64)
+    lib().azo_reset_state(seed, tree, episode, int(bool(cartpole)), _capi._ptr(out, C.c_double))
+    return out[:4 if cartpole else 2].copy()
+
+
+def act_draw(seed, tree, step):
+    """(u01 float32, u float64, raw word) of a self-play step's final-action draw."""
+    u01, u, w = C.c_float(), C.c_double(), C.c_uint32()
+    lib().azo_act_draw(seed, tree, step, C.byref(u01), C.byref(u), C.byref(w))
+    return float(u01.value), float(u.value), int(w.value)
 
 
 def sample_action(mu, sigma, eps, bound):

@@ -1,4 +1,10 @@
-"""Device-resident self-play (azg_selfplay_*): invariants on the oracle (CPU) and bit-exact HIP-vs-oracle rows (GPU)."""
+"""Device-resident self-play (azg_selfplay_*): the reference's run loops as golden vectors (tier T7) against the oracle (CPU)
+and the HIP engine (GPU), the replay ring's FIFO rule against the reference's ReplayBuffer (T6), invariants, and bit-exact
+HIP-vs-oracle rows."""
+import ast
+import glob
+import os
+
 import numpy as np
 import pytest
 
@@ -57,3 +63,208 @@ def test_selfplay_hip_matches_oracle_bit_for_bit(case):
     np.testing.assert_array_equal(a_rows.view(np.uint32), b_rows.view(np.uint32))
     for x, y in zip(a_stats, b_stats):
         np.testing.assert_array_equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------ T7: the reference's run loops
+
+T7 = sorted(os.path.basename(p)[len("t7_selfplay_"):-4] for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t7_selfplay_*.npz")))
+ENGINES = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def _engine_cls(which):
+    if which == "oracle":
+        return O.OracleEngine
+    from alphazero_gym_amd import _native
+    _native.lib()
+    return _native.HipEngine
+
+
+def _t7_engine(cls, case, **over):
+    cont = case["mode"] == 1
+    in_dim, n_dist = (3, 2) if cont else (4, case["num_actions"])
+    e = cls(env_id=case["env_id"], mode=case["mode"], n_trees=case["n_games"], n_sims=case["n_sims"], c_uct=case["c_uct"],
+            gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0), c_pw=case.get("c_pw", 1.0),
+            kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=case["seed"], tree_id_base=case["tree_id_base"])
+    e.set_weights(_capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]),
+                  O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0)))
+    kw = dict(max_episode_length=case["max_len"], deterministic=case.get("det", False), capacity_steps=case["n_steps"],
+              final_selection=case.get("final_selection", "max_visit"), temperature=case.get("temperature", 1.0),
+              agent_epsilon=case.get("agent_eps", 0.0))
+    kw.update(over)
+    e.selfplay_begin(**kw)
+    return e
+
+
+@pytest.mark.parametrize("which", ENGINES)
+@pytest.mark.parametrize("name", T7)
+def test_selfplay_matches_the_reference_run_loop(name, which):
+    """T7 (tests/golden/gen_golden.py run_t7): the reference's ContinuousAgent.act / DiscreteAgent.act + Env.step + reset_mcts /
+    mcts_forward (run_continuous.py:111-142, run_discrete.py:94-122) for several games over episode boundaries.  Per step and
+    game: the replay row buffer.store received, the root the search started from and the count it carried; per game: finished
+    episodes and their returns.  Integers (counts, episode statistics) and actions exactly; float32 row entries to float32
+    rounding of values that agree to 1e-12 in float64."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"t7_selfplay_{name}.npz"))
+    case = ast.literal_eval(str(z["case"]))
+    e = _t7_engine(_engine_cls(which), case)
+    G, n_steps = case["n_games"], case["n_steps"]
+    So, K = e.s_obs, e.kmax
+    roots = []
+    for _ in range(n_steps):
+        roots.append(e.selfplay_stats()[2].copy())
+        e.selfplay_step()
+    rows = e.selfplay_rows(clear=False).reshape(n_steps, G, -1)
+    fsum, fcnt, state = e.selfplay_stats()
+    e.close()
+    np.testing.assert_allclose(np.stack(roots), z["root_before"], rtol=0, atol=1e-12)          # the roots every search started from
+    want = z["rows"]
+    np.testing.assert_array_equal(rows[..., So + K:So + 2 * K], want[..., So + K:So + 2 * K])    # visit counts
+    np.testing.assert_array_equal(rows[..., So:So + K], want[..., So:So + K].astype(np.float32))  # root actions
+    np.testing.assert_allclose(rows[..., :So], want[..., :So], rtol=0, atol=1.2e-7)              # observation (float32)
+    np.testing.assert_allclose(rows[..., So + 2 * K:], want[..., So + 2 * K:], rtol=2e-7, atol=1e-7)   # Q and the value target
+    np.testing.assert_array_equal(fcnt, z["fcnt"])
+    np.testing.assert_allclose(fsum, z["fsum"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(state, z["final_state"], rtol=0, atol=1e-12)
+    # the action every step took shows in the next root (same episode) -- and, for CartPole, in the carried root count
+    if case["mode"] == 0:
+        for s_ in range(1, n_steps):
+            for g in range(G):
+                if z["carry_in"][s_, g] > 0:
+                    assert abs(z["root_before"][s_, g] - z["root_before"][s_ - 1, g]).max() < 1.0
+
+
+@pytest.mark.parametrize("which", ENGINES)
+def test_replay_ring_overwrites_like_the_reference_buffer(which):
+    """The FIFO rule of ReplayBuffer.store (buffers.py:75-82), pinned by the T6 golden (the reference's buffer of max_size 7
+    through 17 stores): one game, ring of 7 steps, 17 steps played; after every step the ring's slots hold the steps the
+    reference's slots hold, and size / insert_index agree."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t6_buffer.npz"))
+    zc = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t7_selfplay_cartpole_sampled.npz"))
+    case = dict(ast.literal_eval(str(zc["case"])), n_games=1)
+    cls = _engine_cls(which)
+    full = _t7_engine(cls, case, capacity_steps=17)                 # the same 17 steps without overwriting: row of step i
+    ring = _t7_engine(cls, case, capacity_steps=7, fifo=True)
+    for i in range(17):
+        full.selfplay_step()
+        ring.selfplay_step()
+        all_rows = full.selfplay_rows(clear=False)
+        got = ring.selfplay_rows(clear=False)
+        slots = z["slots"][i]
+        size, insert = int(slots[8]), int(slots[7])
+        assert ring.selfplay_ring() == (size, insert, i + 1)
+        assert got.shape[0] == size
+        for j in range(size):
+            np.testing.assert_array_equal(got[j], all_rows[int(slots[j])], err_msg=f"after store {i}: slot {j}")
+    ring.selfplay_rows(clear=True)
+    assert ring.selfplay_ring()[:2] == (0, 0)                        # ReplayBuffer.clear (buffers.py:56-60)
+    stop = _t7_engine(cls, case, capacity_steps=2)
+    stop.selfplay_step(); stop.selfplay_step()
+    with pytest.raises(_capi.EngineError):
+        stop.selfplay_step()                                         # AZG_RING_STOP: refuses instead of overwriting
+    for e in (full, ring, stop):
+        e.close()
+
+
+def test_selfplay_config_errors():
+    e = O.OracleEngine(env_id=0, mode=0, n_trees=2, n_sims=4, c_uct=1.5, gamma=1.0, num_actions=2)
+    e.set_weights(_capi.make_desc(4, [64], 2, "relu"), O.make_weights(1, 4, [64], 2))
+    with pytest.raises(_capi.EngineError):
+        e.selfplay_begin(5, final_selection="max_value", temperature=0.5)     # Q-based sampling: temperature 1 only
+    with pytest.raises(_capi.EngineError):
+        e.selfplay_begin(5, temperature=0.0)
+    with pytest.raises(_capi.EngineError):
+        e.selfplay_begin(5, agent_epsilon=1.5)
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", T7)
+def test_selfplay_variants_hip_matches_oracle_bit_for_bit(name):
+    """Every final-action rule of T7 on a larger ragged batch: HIP rows == oracle rows bit for bit."""
+    from alphazero_gym_amd import _native
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"t7_selfplay_{name}.npz"))
+    case = dict(ast.literal_eval(str(z["case"])), n_games=37, n_steps=12)
+    out = []
+    for cls in (_native.HipEngine, O.OracleEngine):
+        e = _t7_engine(cls, case, capacity_steps=5, fifo=True)
+        for _ in range(12):
+            e.selfplay_step()
+        out.append((e.selfplay_rows(clear=False), e.selfplay_stats(), e.selfplay_ring()))
+        e.close()
+    np.testing.assert_array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    for x, y in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(x, y)
+    assert out[0][2] == out[1][2]
+
+
+@pytest.mark.parametrize("which", ENGINES)
+def test_device_replay_samples_like_the_reference_buffer(which):
+    """DeviceReplay = the ring + the reference's minibatch rule (buffers.py:84-123), pinned by the T6 golden: same shuffles under
+    numpy seed 123, same batch sizes (3, 4 = last batch absorbs the remainder), same experiences in every batch, two epochs."""
+    import torch
+    from alphazero_gym_amd.agent.buffers import DeviceReplay
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t6_buffer.npz"))
+    zc = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t7_selfplay_cartpole_sampled.npz"))
+    case = dict(ast.literal_eval(str(zc["case"])), n_games=1)
+    cls = _engine_cls(which)
+    full = _t7_engine(cls, case, capacity_steps=17)
+    ring = _t7_engine(cls, case, capacity_steps=7, fifo=True)
+    for _ in range(17):
+        full.selfplay_step()
+        ring.selfplay_step()
+    all_rows = full.selfplay_rows(clear=False)
+    rep = DeviceReplay(ring, batch_size=3, device="cpu" if which == "oracle" else None)
+    assert len(rep) == 7 and (rep.rows().is_cuda == (which == "hip"))
+    np.testing.assert_array_equal(rep.rows().cpu().numpy(), ring.selfplay_rows(clear=False))      # zero-copy view == download
+    np.random.seed(123)
+    rep.reshuffle()
+    got = []
+    for epoch in range(2):
+        for states, actions, counts, Qs, values in rep:
+            assert states.shape[1] == 4 and actions.shape[1] == counts.shape[1] == Qs.shape[1] == 2 and values.ndim == 1
+            rows = torch.cat([states, actions, counts, Qs, values[:, None]], 1).cpu().numpy()
+            ids = [int(np.where((all_rows == r).all(1))[0][0]) for r in rows]                        # which step each row is
+            got.append([epoch, len(ids)] + ids + [-1] * (8 - len(ids)))
+    np.testing.assert_array_equal(np.array(got), z["batches"])
+    # the view aliases the ring: another step shows up without re-wrapping
+    before = rep.rows().clone()
+    ring.selfplay_step()
+    assert not torch.equal(before, rep.rows())
+    full.close(); ring.close()
+
+
+@pytest.mark.gpu
+def test_training_from_the_device_ring_without_a_host_copy():
+    """DeviceSelfPlay.collect_device + train_on_rows with the policy on the GPU: rows stay device tensors from the ring to the
+    optimiser step; same rows as the host download path."""
+    import torch
+    from alphazero_gym_amd import run
+    from alphazero_gym_amd.agent.agents import ContinuousAgent
+    cfg = run.CONTINUOUS_DEFAULTS
+    policy = dict(cfg["policy"], hidden_dimensions=[64, 64], representation_dim=3, action_dim=1, action_bound=2.0)
+    torch.manual_seed(0)
+    agent = ContinuousAgent(policy_cfg=policy, mcts_cfg=dict(cfg["mcts"], n_rollouts=16, device="cuda:0"), loss_cfg=dict(run.LOSS_TUNED, device="cuda:0"),
+                            optimizer_cfg=run.RMSPROP, device="cuda:0", **cfg["agent"])
+    kw = dict(game="Pendulum-v1", n_games=48, n_rollouts=16, c_uct=0.05, max_episode_length=20, seed=3)
+    sp_fifo = run.DeviceSelfPlay(agent.nn, capacity_steps=4, fifo=True, **kw)
+    sp_host = run.DeviceSelfPlay(agent.nn, capacity_steps=6, **kw)
+    rep = sp_fifo.replay(batch_size=32)
+    for it in range(3):   # 6 steps per iteration through a ring of 4: wraps every time
+        dev_rows = sp_fifo.collect_device(3, rep)
+        host_rows = sp_host.collect(3)
+        assert dev_rows.is_cuda and dev_rows.shape == (3 * 48, sp_fifo.engine.s_obs + 3 * sp_fifo.engine.kmax + 1)
+        np.testing.assert_array_equal(dev_rows.cpu().numpy(), host_rows.numpy())
+    w0 = [p.detach().clone() for p in agent.nn.parameters()]
+    info = run.train_on_rows(agent, dev_rows, 3, sp_fifo.engine.kmax, batch_size=32)
+    assert np.isfinite(info["loss"]) and any(not torch.equal(a, b) for a, b in zip(w0, agent.nn.parameters()))
+    rep.reshuffle()
+    n = 0
+    for states, actions, counts, Qs, values in rep:
+        assert states.is_cuda
+        info = agent.update((states, actions, counts, Qs, values))
+        n += 1
+    assert n == (4 * 48) // 32 and np.isfinite(info["loss"])
+    # the next self-play step runs with the trained weights
+    from alphazero_gym_amd.search.mcts import _weights_version
+    stale = sp_fifo.mcts._version
+    sp_fifo.play(1)
+    assert sp_fifo.mcts._version == _weights_version(agent.nn) != stale
