@@ -180,6 +180,11 @@ class DeviceReplay:
         self._sampler = _EpochSampler(self.batch_size)
 
     @property
+    def ring(self):
+        """The whole ring [capacity_rows, row_len] as a zero-copy tensor (slots beyond ``size`` are undefined)."""
+        return self._ring
+
+    @property
     def size(self) -> int:
         """Valid rows (ReplayBuffer.size in rows)."""
         return self.engine.selfplay_ring()[0] * self.engine.n_trees

@@ -1,29 +1,47 @@
 #!/usr/bin/env python3
 """Headline benchmark: MCTS simulations / second, Pendulum-v1, 4096 trees per GPU, n_sims=200, 2x256 ELU MLP
-(BASELINE.json `metric`, config C; config D = the same on 8 GPUs, weak scaling, one process per GPU).
+(BASELINE.json `metric`).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one whole search (B trees x n_sims simulations) over synthetic fixed-seed root states that are already
-resident in HBM; each step is ONE launch of the fused search kernel.  Rank 0 prints one JSON line.
+N = 1  (config C): a "step" is one whole search (4096 trees x 200 simulations = ONE launch of the fused search kernel) over
+       synthetic fixed-seed root states already resident in HBM.  The JSON line also carries `extra`: configs B and E timed
+       the same way, the PCIe-inclusive rate of config C, and the CPU baselines.
+N > 1  (config D): one process per GPU (spawned here when the script was not started by torch.distributed.run), 4096 self-play
+       games per GPU keyed by global game id.  A step is one device-resident self-play step (search + final action + env step +
+       replay row) PLUS the all-gather of the step's replay rows over RCCL (HBM to HBM, overlapped with the next step's search)
+       and a weight broadcast + engine re-sync every --bcast-every steps: the loop shape of run_continuous.py:111-155 scaled out.
+       `extra.search_only` is the same loop without the collectives.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
 N_TREES, N_SIMS, HIDDEN = 4096, 200, [256, 256]
-FLOP_PER_SIM = 2 * (3 * 256 + 256 * 256 + 256 * 3)   # 134 144 FLOP per fused policy/value evaluation
-PEAK_TFLOPS = 157.3                                    # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PENDULUM = dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+CARTPOLE = dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+
+
+def mlp_flops(in_dim, hidden, n_out):
+    """2 * sum(in * out) of one fused policy/value evaluation."""
+    dims = [in_dim] + list(hidden)
+    return 2 * (sum(a * b for a, b in zip(dims[:-1], dims[1:])) + hidden[-1] * n_out)
+
+
+FLOP_PER_SIM = mlp_flops(3, HIDDEN, 3)   # 134 144
 
 
 def profiled_traffic():
@@ -33,7 +51,7 @@ def profiled_traffic():
     for this kernel's narrow reads).  None when no profile is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")) if "config" not in os.path.basename(f))
     if not files:
         return None
     vals = {}
@@ -44,32 +62,110 @@ def profiled_traffic():
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def cpu_baseline(seconds_target=15.0):
-    """The C oracle (a scalar port of the reference's per-tree algorithm) on this box's host cores, OpenMP over trees,
-    on a bounded sample of the same workload."""
-    import oracle_lib as O
-    from alphazero_gym_amd import _capi
+def physical_cores():
+    """Distinct (package, core) pairs; falls back to the logical count."""
+    seen = set()
+    try:
+        for d in os.listdir("/sys/devices/system/cpu"):
+            if d.startswith("cpu") and d[3:].isdigit():
+                t = f"/sys/devices/system/cpu/{d}/topology/"
+                seen.add((open(t + "physical_package_id").read().strip(), open(t + "core_id").read().strip()))
+    except OSError:
+        pass
+    return len(seen) or (os.cpu_count() or 1)
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+
+def cpu_baseline():
+    """CPU lines next to the GPU number, each on a bounded sample of the same workload:
+      * the C oracle (scalar port of the per-tree algorithm, OpenMP over trees, trees allocated by their worker thread) on one
+        thread and on one thread per physical core;
+      * the Python object-tree restatement with the reference's cost structure (oracle/pytree.py: batch-1 torch-CPU forwards,
+        env replay from the root, numpy UCT), P worker processes x 1 torch thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    import pytree
+    from alphazero_gym_amd import _capi
+    from alphazero_gym_amd.synthetic import make_weights
+
+    cores = physical_cores()
     desc = _capi.make_desc(3, HIDDEN, 2, "elu")
-    blob = O.make_weights(34, 3, HIDDEN, 2)
-    n = max(cores, 8)
-    kw = dict(env_id=2, mode=1, n_sims=N_SIMS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
-    e = O.OracleEngine(n_trees=n, **kw)
-    e.set_weights(desc, blob)
-    roots = e.synthetic_roots()
-    t0 = time.perf_counter(); e.search(roots); dt = time.perf_counter() - t0
-    rate = n * N_SIMS / dt
-    e.close()
-    n2 = int(min(N_TREES, max(n, rate * seconds_target / N_SIMS)))
-    e = O.OracleEngine(n_trees=n2, **kw)
-    e.set_weights(desc, blob)
-    roots = e.synthetic_roots()
-    t0 = time.perf_counter(); e.search(roots); dt = time.perf_counter() - t0
-    e.close()
-    return {"value": n2 * N_SIMS / dt, "unit": "sims/s", "cores": cores, "kind": "port",
-            "sample": f"{n2} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle + OpenMP, {dt:.1f} s"}
+    blob = make_weights(34, 3, HIDDEN, 2)
+
+    def oracle_rate(threads, n_trees, seconds=0.0):
+        """searches of n_trees trees until `seconds` have passed (at least one, after an untimed one that allocates the trees)"""
+        O.set_threads(threads)
+        e = O.OracleEngine(n_trees=n_trees, n_sims=N_SIMS, **PENDULUM)
+        e.set_weights(desc, blob)
+        roots = e.synthetic_roots()
+        if seconds > 0:
+            e.search(roots)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            e.search(roots)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+        e.close()
+        return reps * n_trees * N_SIMS / dt, dt, reps
+
+    r1, _, _ = oracle_rate(1, 16)                                  # ~0.3 s: sizes the samples
+    n1 = int(max(16, min(N_TREES, r1 * 2.0 / N_SIMS)))
+    r1, dt1, reps1 = oracle_rate(1, n1, 4.0)
+    nall = int(max(cores, min(N_TREES, r1 * cores * 2.0 / N_SIMS)))
+    rall, dtall, repsall = oracle_rate(cores, nall, 8.0)
+    procs = min(cores, 64)
+    t0 = time.perf_counter()
+    rpy = pytree.throughput("pendulum", n_rollouts=N_SIMS, hidden=HIDDEN, processes=procs, trees_per_process=2)
+    dtpy = time.perf_counter() - t0
+    return {"value": rall, "unit": "sims/s", "cores": cores, "kind": "port",
+            "sample": f"{repsall} searches of {nall} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle, OpenMP over trees on "
+                      f"{cores} threads (one per physical core of {os.cpu_count()} logical CPUs), {dtall:.1f} s",
+            "single_thread": {"value": r1, "unit": "sims/s", "cores": 1, "sample": f"{reps1} searches of {n1} trees x {N_SIMS} sims, {dt1:.1f} s"},
+            "python_object_tree": {"value": rpy, "unit": "sims/s", "cores": procs, "kind": "port",
+                                   "sample": f"{procs} processes x 2 trees x {N_SIMS} sims, 1 torch thread each, oracle/pytree.py "
+                                             f"(the reference's cost structure: batch-1 torch forwards, env replay, numpy UCT), {dtpy:.1f} s incl. start-up"}}
+
+
+def time_search(eng, steps, warmup):
+    """(median, mean) kernel milliseconds of `steps` resident searches by HIP events on the engine's stream."""
+    for _ in range(warmup):
+        eng.search_resident()
+    eng.sync()
+    ms = []
+    for _ in range(steps):
+        eng.search_resident()
+        ms.append(eng.last_search_ms())
+    return float(np.median(ms)), float(np.mean(ms))
+
+
+def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, kernels, flops_per_sim, note, device_id):
+    from alphazero_gym_amd import _capi, _native
+    from alphazero_gym_amd.synthetic import make_weights
+    eng = _native.HipEngine(n_trees=trees, n_sims=n_sims, device_id=device_id, **kw)
+    eng.set_weights(_capi.make_desc(in_dim, hidden, n_dist, act), make_weights(34, in_dim, hidden, n_dist))
+    eng.upload_roots(eng.synthetic_roots())
+    med, mean = time_search(eng, 7, 2)
+    res = eng.results()
+    assert (res["counts"].sum(1) == n_sims).all()
+    eng.close()
+    ach = trees * n_sims * flops_per_sim / (med * 1e-3) / 1e12
+    return {"config": name, "ms_per_search": med, "ms_mean": mean, "sims_per_s": trees * n_sims / (med * 1e-3), "trees": trees, "n_sims": n_sims,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS}, "kernels": kernels,
+            "note": note}
+
+
+def spawn(args):
+    """`--gpus N` without torch.distributed.run around us: start it as a child process (this process has not touched the GPU
+    or torch) and exit with its code; the child's rank 0 prints the JSON line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--backend", args.backend]
+    if args.same_device:
+        cmd.append("--same-device")
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -77,31 +173,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--trees", type=int, default=N_TREES)
+    ap.add_argument("--trees", type=int, default=N_TREES, help="trees (games) per GPU")
+    ap.add_argument("--bcast-every", type=int, default=10, help="N > 1: weight broadcast + engine re-sync every this many steps")
+    ap.add_argument("--backend", default="nccl", help="N > 1: nccl (= RCCL) or gloo (functional test of the loop on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="N > 1: every rank on GPU 0 (functional test on a 1-GPU box, with gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the config B / E lines")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    dev = 0 if args.same_device else local_rank
     import torch
 
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
-    import oracle_lib as O   # make_weights only (numpy); the oracle library itself is used by cpu_baseline() alone
     from alphazero_gym_amd import _capi, _native
+    from alphazero_gym_amd.synthetic import make_weights
 
     B = args.trees
-    eng = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=N_SIMS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34,
-                            tree_id_base=rank * B, device_id=local_rank)
-    eng.set_weights(_capi.make_desc(3, HIDDEN, 2, "elu"), O.make_weights(34, 3, HIDDEN, 2))
+    desc, blob = _capi.make_desc(3, HIDDEN, 2, "elu"), make_weights(34, 3, HIDDEN, 2)
+    eng = _native.HipEngine(n_trees=B, n_sims=N_SIMS, tree_id_base=rank * B, device_id=dev, **PENDULUM)
+    eng.set_weights(desc, blob)
     eng.upload_roots(eng.synthetic_roots())
 
     def barrier():
@@ -109,48 +214,122 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.search_resident()
-    eng.sync()
-    kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.search_resident()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # per-launch kernel duration from HIP events on the engine's stream (separate pass, so the event reads don't
-    # serialise the timed loop)
-    for _ in range(min(args.steps, 10)):
-        eng.search_resident()
-        kernel_ms.append(eng.last_search_ms())
+    extra = {}
+    if world == 1:
+        # ---------------- config C: K whole searches, roots resident in HBM
+        for _ in range(args.warmup):
+            eng.search_resident()
+        eng.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.search_resident()
+        eng.sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kmed, kmean = time_search(eng, min(args.steps, 10), 0)   # separate pass: the event reads would serialise the timed loop
+        res = eng.results()
+        assert (res["counts"].sum(1) == N_SIMS).all()
+        # the boundary with host buffers (azg_search uploads the roots, azg_results downloads the root statistics over PCIe)
+        roots = eng.synthetic_roots()
+        pc = []
+        for _ in range(5):
+            t1 = time.perf_counter(); eng.search(roots); eng.results(); pc.append(time.perf_counter() - t1)
+        extra["pcie_inclusive"] = {"sims_per_s": B * N_SIMS / float(np.median(pc)), "ms_per_search": float(np.median(pc)) * 1e3,
+                                   "note": "azg_search (host roots in) + azg_results (host root statistics out), median of 5; never `value`"}
+        workload = f"config C: Pendulum-v1 A0C, {B} trees/GPU x {N_SIMS} sims, 2x256 ELU policy/value MLP, c_uct=0.05 c_pw=1 kappa=0.5"
+        parallelism = "1 GPU"
+    else:
+        # ---------------- config D: self-play steps + replay all-gather + weight broadcast
+        from alphazero_gym_amd.agent.buffers import DeviceReplay
+        eng.selfplay_begin(200, capacity_steps=2, fifo=True)
+        ring = DeviceReplay(eng, batch_size=32).ring.reshape(2, B, -1)   # zero-copy torch view of the device ring
+        RL = ring.shape[-1]
+        on_host = args.backend != "nccl"
+        gathered = torch.empty((world * B, RL), dtype=torch.float32, device="cpu" if on_host else ring.device)
+        flat = torch.from_numpy(blob.copy()).to(ring.device)
+
+        def run(steps, collectives):
+            """`steps` self-play steps; with collectives, step s-1's rows are all-gathered while step s searches."""
+            for s in range(steps):
+                eng.sync()                                        # step s-1 finished (it ran while the host did the last gather)
+                if collectives and s > 0 and s % args.bcast_every == 0:
+                    dist.broadcast(flat, src=0)                   # updated weights from the trainer rank ...
+                    eng.set_weights(desc, flat.cpu().numpy())     # ... into every rank's engine
+                eng.selfplay_step()                               # launches only: step s now runs on the engine's stream
+                if collectives and s > 0:
+                    rows = ring[(s - 1) % 2]
+                    dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
+                    torch.cuda.current_stream().synchronize()     # slot (s-1)%2 is free again before step s+1 is launched
+            eng.sync()
+            if collectives and steps > 0:
+                rows = ring[(steps - 1) % 2]
+                dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
+                torch.cuda.current_stream().synchronize()
+
+        run(args.warmup, True)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        t1 = time.perf_counter()
+        run(args.steps, False)
+        barrier()
+        plain = time.perf_counter() - t1
+        counts = gathered[:, 3 + eng.kmax:3 + 2 * eng.kmax].sum(1)
+        assert bool((counts == N_SIMS).all()), "a gathered replay row does not hold n_sims visits"
+        kmed, kmean = time_search(eng, 5, 0)
+        workload = (f"config D: Pendulum-v1 A0C self-play, {world * B} games = {B} per GPU x {N_SIMS} sims per move, 2x256 ELU MLP; per step: "
+                    f"search + final action + env step + replay row on the device, all-gather of the step's {world * B} replay rows "
+                    f"({world * B * RL * 4 / 1e6:.1f} MB) and a weight broadcast + engine re-sync every {args.bcast_every} steps")
+        parallelism = f"{world} ranks x {B} games (games sharded by global id; RCCL all-gather + broadcast outside the search)"
+        if args.backend != "nccl":
+            parallelism += f" [functional run: backend {args.backend}, rows staged through the host]"
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cpu" if args.backend != "nccl" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    res = eng.results()
-    assert (res["counts"].sum(1) == N_SIMS).all()
+        if world > 1:
+            t = torch.tensor([plain], device="cpu" if args.backend != "nccl" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            plain = float(t.item())
     eng.close()
     if rank == 0:
         sims = world * B * N_SIMS * args.steps
-        kms = float(np.mean(kernel_ms))
-        achieved = B * N_SIMS * FLOP_PER_SIM / (kms * 1e-3) / 1e12
+        achieved = B * N_SIMS * FLOP_PER_SIM / (kmean * 1e-3) / 1e12
+        if world > 1:
+            extra["search_only"] = {"sims_per_s": sims / plain, "ms_per_step": plain / args.steps * 1e3,
+                                    "note": "the same self-play loop without the all-gather and the weight broadcast"}
+        elif not args.no_extra:
+            extra["configs"] = [
+                extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
+                             ["search_kernel<0, 128, 1, 1, false, 4, 1>"], 0.26 * mlp_flops(4, [128, 128], 3),
+                             "tree-walk bound (9.2 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction", dev),
+                extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
+                             ["ls_tree_kernel<2, false, 16>", "ls_hidden_tiled_kernel<1024, false, 2, 4>", "ls_hidden_tiled_kernel<1024, true, 2, 4>"],
+                             mlp_flops(3, [1024] * 4, 3), "lock-step path: per simulation step one tree kernel + one kernel per hidden layer", dev),
+            ]
         out = {
             "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Pendulum-v1 A0C, {B} trees/GPU x {N_SIMS} sims, 2x256 ELU policy/value MLP, c_uct=0.05 c_pw=1 kappa=0.5",
-                       "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": f"{world} independent shards (no data-path collective)"},
+            "config": {"workload": workload, "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": profiled_traffic(), "kernel": "search_kernel<2, 256, 1, 1, false, 4, 1> (ENV=Pendulum, HP=256, NREG=1, trees in LDS with 8-bit ids, no GMM, 4 waves, 1 tree group)", "kernel_ms": kms,
+                         "traffic": profiled_traffic() if B == N_TREES else None,
+                         "kernel": "search_kernel<2, 256, 1, 1, false, 4, 1> (ENV=Pendulum, HP=256, NREG=1, trees in LDS with 8-bit ids, no GMM, 4 waves, 1 tree group)"
+                                   if B <= 4096 else "search_kernel<2, 256, 1, 1, false, 8, 2> (8 waves, 2 tree groups per workgroup)",
+                         "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/)"},
+            "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

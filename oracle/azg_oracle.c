@@ -28,6 +28,9 @@
  *   network/policies.py:101-120, 150-160, 238-259, 340-352, 436-464, 488-499 -> mlp_forward()
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -102,6 +105,17 @@ static int fail(azg_engine* e, int code, const char* msg) {
 }
 
 int azo_abi_version(void) { return AZG_ABI_VERSION; }
+
+/* worker threads of the OpenMP loop over trees (bench.py's cpu_baseline: one per physical core, or 1) */
+int azo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 const char* azo_last_error(const azg_engine* e) { return e ? e->err : g_create_err; }
 
 /* ------------------------------------------------------------------ environments (float64) */
@@ -291,6 +305,17 @@ static void evaluate_obs(const azg_engine* e, const float* obs, float* V, float*
 
 /* ------------------------------------------------------------------ engine */
 
+static void alloc_tree(const azg_engine* e, tree_t* t) {
+    int R = e->R;
+    t->parent = (int32_t*)calloc(R, 4); t->edge_n = (int32_t*)calloc(R, 4);
+    t->edge_W = (double*)calloc(R, 8); t->edge_Q = (double*)calloc(R, 8);
+    t->edge_action = (float*)calloc(R, 4); t->node_n = (int32_t*)calloc(R, 4);
+    t->node_r = (double*)calloc(R, 8); t->node_V = (float*)calloc(R, 4);
+    t->flags = (uint8_t*)calloc(R, 1); t->state = (double*)calloc((size_t)R * e->S_env, 8);
+    t->dist = (float*)calloc((size_t)R * e->n_dist, 4); t->n_child = (int32_t*)calloc(R, 4);
+    t->child = (int32_t*)calloc((size_t)R * e->Kmax, 4);
+}
+
 static void free_tree(tree_t* t) {
     free(t->parent); free(t->edge_n); free(t->edge_W); free(t->edge_Q); free(t->edge_action);
     free(t->node_n); free(t->node_r); free(t->node_V); free(t->flags); free(t->state); free(t->dist);
@@ -340,18 +365,8 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
         e->R = 1 + cfg->num_actions * (ns + 1);
         e->n_dist = cfg->num_actions;
     }
+    /* per-tree arrays are allocated by the thread that first searches the tree (first touch: pages land on its NUMA node) */
     e->trees = (tree_t*)calloc(cfg->n_trees, sizeof(tree_t));
-    for (int i = 0; i < cfg->n_trees; ++i) {
-        tree_t* t = &e->trees[i];
-        int R = e->R;
-        t->parent = (int32_t*)calloc(R, 4); t->edge_n = (int32_t*)calloc(R, 4);
-        t->edge_W = (double*)calloc(R, 8); t->edge_Q = (double*)calloc(R, 8);
-        t->edge_action = (float*)calloc(R, 4); t->node_n = (int32_t*)calloc(R, 4);
-        t->node_r = (double*)calloc(R, 8); t->node_V = (float*)calloc(R, 4);
-        t->flags = (uint8_t*)calloc(R, 1); t->state = (double*)calloc((size_t)R * e->S_env, 8);
-        t->dist = (float*)calloc((size_t)R * e->n_dist, 4); t->n_child = (int32_t*)calloc(R, 4);
-        t->child = (int32_t*)calloc((size_t)R * e->Kmax, 4);
-    }
     e->roots = (double*)calloc((size_t)cfg->n_trees * e->S_env, 8);
     e->carry = (int32_t*)calloc(cfg->n_trees, 4);
     *out = e;
@@ -370,7 +385,8 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         if (d->n_dist != (C ? 3 * C : 2)) return fail(e, AZG_E_INVALID, "n_dist does not match num_components");
         if (d->n_dist != e->n_dist) {
             /* the per-node distribution cache is sized by n_dist */
-            for (int i = 0; i < e->cfg.n_trees; ++i) { free(e->trees[i].dist); e->trees[i].dist = (float*)calloc((size_t)e->R * d->n_dist, 4); }
+            for (int i = 0; i < e->cfg.n_trees; ++i)
+                if (e->trees[i].parent) { free(e->trees[i].dist); e->trees[i].dist = (float*)calloc((size_t)e->R * d->n_dist, 4); }
             e->n_dist = d->n_dist;
         }
         e->mlp.ncomp = C;
@@ -604,9 +620,11 @@ int azo_search_resident(azg_engine* e) {
     if (!e->mlp.ready) return fail(e, AZG_E_STATE, "azo_set_weights has not been called");
     int B = e->cfg.n_trees;
     uint32_t sidx = e->search_idx;
-#pragma omp parallel for schedule(dynamic, 4)
+    /* static schedule: a tree is searched by the thread that allocated it (see alloc_tree) */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < B; ++i) {
         ctx_t c;
+        if (!e->trees[i].parent) alloc_tree(e, &e->trees[i]);
         c.e = e; c.t = &e->trees[i]; c.gtree = (uint32_t)(e->cfg.tree_id_base + i); c.search = sidx; c.eps_draws = 0;
         search_tree(&c, e->roots + (size_t)i * e->S_env, e->carry[i]);
     }

@@ -121,34 +121,9 @@ def env_step(env_id, state, action):
     return nxt, r.value, bool(d.value), obs
 
 
-def make_weights(seed, in_dim, hidden, n_dist, scale=1.0):
-    """Deterministic synthetic weights, torch nn.Linear default-init ranges (U(-1/sqrt(fan_in), 1/sqrt(fan_in))),
-    drawn from numpy's PCG64 so that fixtures only need to store the seed."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    parts = []
-    k = in_dim
-    for h in list(hidden):
-        b = 1.0 / np.sqrt(k)
-        parts.append(rng.uniform(-b, b, size=(h, k)).astype(np.float32).ravel() * np.float32(scale))
-        parts.append(rng.uniform(-b, b, size=(h,)).astype(np.float32))
-        k = h
-    b = 1.0 / np.sqrt(k)
-    parts.append(rng.uniform(-b, b, size=(1, k)).astype(np.float32).ravel())
-    parts.append(rng.uniform(-b, b, size=(1,)).astype(np.float32))
-    parts.append(rng.uniform(-b, b, size=(n_dist, k)).astype(np.float32).ravel() * np.float32(scale))
-    parts.append(rng.uniform(-b, b, size=(n_dist,)).astype(np.float32))
-    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+from alphazero_gym_amd.synthetic import add_layernorm, make_weights  # noqa: E402,F401  (re-exported: fixtures store seeds only)
 
 
-def add_layernorm(blob, in_dim, hidden, n_dist, seed):
-    """Insert LayerNorm weight/bias (same PCG64 draws as gen_golden.set_layernorm_params) after every trunk layer of a
-    make_weights blob: per layer W, b, ln_w, ln_b."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    parts, p, k = [], 0, in_dim
-    for h in hidden:
-        parts.append(blob[p:p + h * k + h]); p += h * k + h
-        parts.append(rng.uniform(0.5, 1.5, (h,)).astype(np.float32))
-        parts.append(rng.uniform(-0.3, 0.3, (h,)).astype(np.float32))
-        k = h
-    parts.append(blob[p:])
-    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+def set_threads(n):
+    """Worker threads of the oracle's OpenMP loop over trees; returns the count in effect."""
+    return int(lib().azo_set_threads(int(n)))

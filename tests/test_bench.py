@@ -1,0 +1,39 @@
+"""bench.py: the pieces that run without a GPU, and (-m gpu) its N > 1 loop end to end on one GPU (gloo, every rank on GPU 0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_flop_and_core_counts():
+    import bench
+    assert bench.FLOP_PER_SIM == 134144                            # 2x256 Pendulum
+    assert bench.mlp_flops(3, [1024] * 4, 3) == 6303744            # config E
+    assert bench.mlp_flops(4, [128, 128], 3) == 34560              # config B, per evaluation
+    assert 1 <= bench.physical_cores() <= (os.cpu_count() or 1)
+
+
+def test_gpus_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_multi_rank_loop_on_one_gpu():
+    """`python bench.py --gpus 2` spawns its own ranks; config D's step (self-play step, all-gather of the step's rows, weight
+    broadcast + engine re-sync) runs with gloo and both ranks on GPU 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--trees", "512",
+                        "--bcast-every", "2", "--backend", "gloo", "--same-device"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["extra"]["search_only"]["sims_per_s"] >= out["value"] * 0.5
+    assert "config D" in out["config"]["workload"]
