@@ -72,17 +72,25 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
 // ---- lock-step path (wide networks): a few grid-wide launches per simulation step
 static int ls_prepare(azg_engine* e) {
     if (e->ls_hp == e->HP) return AZG_OK;
+    if (e->ls_graph_exec) { (void)hipGraphExecDestroy(e->ls_graph_exec); e->ls_graph_exec = nullptr; }
     for (void* p : e->ls_allocs) (void)hipFree(p);
     e->ls_allocs.clear();
+    if (!e->ls_fork) {
+        if (hipEventCreateWithFlags(&e->ls_fork, hipEventDisableTiming) != hipSuccess) return fail(e, AZG_E_DEVICE, "hipEventCreate failed");
+        for (int p = 1; p < LS_MAX_PIPES; ++p)
+            if (hipStreamCreateWithFlags(&e->ls_streams[p], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ls_join[p], hipEventDisableTiming) != hipSuccess)
+                return fail(e, AZG_E_DEVICE, "stream / event creation for the lock-step pipelines failed");
+    }
     // tree groups padded to a multiple of 4: the tiled layer kernel works on 4 groups per workgroup
     const size_t B = e->cfg.n_trees, G = ((B + TREES_PER_WG - 1) / TREES_PER_WG + 3) / 4 * 4, HP = e->HP;
     float* obsT; float *a0, *a1, *parts; LsTree* tr; LsLane* ln;
-    if (dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
+    if (dalloc(e, &e->d_ls_sidx, (size_t)4, e->ls_allocs) || dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
         dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
         dalloc(e, &ln, B * 16, e->ls_allocs))
         return AZG_E_DEVICE;
     e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts;
-    e->ls.tree = tr; e->ls.lane = ln;
+    e->ls.tree = tr; e->ls.lane = ln; e->ls.search_idx = e->d_ls_sidx;
     // the padding groups are computed like the others (their columns never mix with real ones): give them defined inputs
     if (hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
     e->ls_hp = e->HP;
@@ -115,6 +123,12 @@ void azg_engine_destroy(azg_engine* e) {
     if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
+    if (e->ls_graph_exec) (void)hipGraphExecDestroy(e->ls_graph_exec);
+    for (int p = 0; p < LS_MAX_PIPES; ++p) {
+        if (e->ls_streams[p]) (void)hipStreamDestroy(e->ls_streams[p]);
+        if (e->ls_join[p]) (void)hipEventDestroy(e->ls_join[p]);
+    }
+    if (e->ls_fork) (void)hipEventDestroy(e->ls_fork);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -143,6 +157,10 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.groups = env_digit("AZG_GROUPS", 0);
     e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
     e->opt.ls_graph = env_digit("AZG_LS_GRAPH", 1);
+    e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 2);
+    e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 1);
+    for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
+    e->ls_fork = nullptr; e->d_ls_sidx = nullptr; e->ls_graph_exec = nullptr; e->ls_graph_pipes = 0;
     e->carry_max = 0;
     e->d_wblob = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
     e->d_eval = nullptr; e->eval_floats = 0;

@@ -18,7 +18,10 @@ struct EngineOptions {
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
     int ls_graph;              // AZG_LS_GRAPH=0: plain launches instead of a captured hipGraph on the lock-step path
+    int ls_pipes;              // AZG_LS_PIPES=n: independent pipelines (streams) the lock-step path cuts the batch into
+    int ls_fuse0;              // AZG_LS_FUSE0=0: the first layer as a launch of its own instead of the tree kernel's tail
 };
+#define LS_MAX_PIPES 8
 
 struct azg_engine {
     azg_config cfg;
@@ -52,6 +55,12 @@ struct azg_engine {
     uint32_t sp_step_idx;
     int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
     std::vector<void*> sp_allocs;
+    hipStream_t ls_streams[LS_MAX_PIPES];   // [0] unused (the engine's stream)
+    hipEvent_t ls_fork, ls_join[LS_MAX_PIPES];
+    unsigned* d_ls_sidx;
+    hipGraphExec_t ls_graph_exec;
+    KParams ls_graph_key;
+    int ls_graph_pipes;
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;

@@ -1,8 +1,9 @@
 // lockstep.cuh -- wide policy/value networks (hidden width >= 512; BASELINE config E: 4x1024): one simulation step = a few
 // grid-wide launches instead of one persistent kernel, so that a network layer of ALL trees is spread over ALL CUs.
-//   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand); trees and
-//                      the per-tree state live in global memory between launches
-//   ls_layer0_kernel   first layer for (tree group, 256-unit slice)
+//   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand), then the
+//                      first network layer of the new leaves (K = obs_dim <= 4: one MFMA k-step per tile) straight from the
+//                      observations it holds in LDS; trees and the per-tree state live in global memory between launches
+//   ls_layer0_kernel   first layer for (tree group, 256-unit slice) as a launch of its own (AZG_LS_FUSE0=0, diagnostics)
 //   ls_hidden_tiled_kernel   one hidden->hidden layer as an LDS-tiled GEMM, 32 trees x 64 units per workgroup, both operands
 //                      double-buffered through LDS, two workgroups per CU; the last layer also leaves the partial head sums
 //   ls_hidden_kernel   the earlier form of that layer (16 trees x 256 units, weights streamed from L2 into registers), kept
@@ -15,13 +16,18 @@
 #include "tree.cuh"
 #include "tree_phases.cuh"
 
-template <int ENV, bool GMM, int NCH>
-__global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int sim) {
+// The batch can be cut into several independent pipelines (ranges of tree groups), each with its own launch sequence on its own
+// stream: one pipeline's tree kernel (few workgroups, latency-bound) then runs beside the other pipelines' layer kernels.
+// g_base = first tree group of the launching pipeline.  FUSE0: compute the first layer in this kernel's tail.
+template <int ENV, bool GMM, int NCH, int HP, bool FUSE0>
+__global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int sim, int g_base) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2]
+    __shared__ float s_obs[64];         // [4][16] observations of the group's new leaves (FUSE0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     const int tl = wave * 4 + (lane >> 4);
-    const int tg = blockIdx.x;
+    const int tg = g_base + blockIdx.x;
+    P.search_idx = *L.search_idx;       // kept in device memory so that a captured launch graph can be replayed for any search
     const int tree = tg * TREES_PER_WG + tl;
     const bool live = tree < P.B;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
@@ -29,6 +35,7 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
     int* s_pw = (int*)(s_dyn + P.tab_n);
     for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
+    if (FUSE0 && tid < 64) s_obs[tid] = 0.0f;   // a trace that ends on a terminal node leaves its column as it is: defined input
     __syncthreads();
     const size_t tb = (size_t)(live ? tree : 0) * P.R;
     Cold* cold = P.cold + tb;
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
     ts.hot = P.hot + tb;
     ts.child = P.child + tb * P.Kp;
     ts.prior = P.prior + tb;
-    float* obsT = L.obsT + (size_t)tg * 64;
+    float* obsT = FUSE0 ? s_obs : L.obsT + (size_t)tg * 64;
     TreeState st;
     if (sim == -2) {
         tree_init_root<ENV, false>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, obsT);
@@ -61,6 +68,21 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
             P.n_rec[tree] = st.nrec;
         }
     }
+    if constexpr (FUSE0) {
+        if (sim < P.n_sims - 1) {
+            __syncthreads();
+            // first layer of the 16 new leaves: this wave's HP/64 output tiles, D = W0 (A operand) x obs (B operand) + b0
+            const float b = s_obs[lane];
+            f32x4* out = L.act[0] + (size_t)tg * (HP / 16) * 64;
+            constexpr int NT0 = HP / 64;
+#pragma unroll 4
+            for (int i = 0; i < NT0; ++i) {
+                const int tile = wave * NT0 + i;
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[tile * 64 + lane], b, P.b0[tile * 64 + lane], 0, 0, 0);
+                out[tile * 64 + lane] = act4<true>(P.act, acc);
+            }
+        }
+    }
     if (live) {
         if (sub == 0) {
             LsTree t;
@@ -75,9 +97,9 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
 }
 
 template <int HP>
-__global__ __launch_bounds__(256) void ls_layer0_kernel(KParams P, LockStep L) {
+__global__ __launch_bounds__(256) void ls_layer0_kernel(KParams P, LockStep L, int g_base) {
     constexpr int NS = HP / 256;
-    const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
+    const int tg = g_base + blockIdx.x / NS, sl = blockIdx.x % NS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float b = L.obsT[(size_t)tg * 64 + lane];
     f32x4* out = L.act[0] + (size_t)tg * (HP / 16) * 64;
@@ -90,10 +112,10 @@ __global__ __launch_bounds__(256) void ls_layer0_kernel(KParams P, LockStep L) {
 }
 
 template <int HP, bool LAST>
-__global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, int layer, int in_buf) {
+__global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, int layer, int in_buf, int g_base) {
     constexpr int NS = HP / 256, S4 = HP / 16;
     extern __shared__ f32x4 s_in[];   // the tree group's input activations: HP/16 tiles x 64 lanes
-    const int tg = blockIdx.x / NS, sl = blockIdx.x % NS;
+    const int tg = g_base + blockIdx.x / NS, sl = blockIdx.x % NS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: weight addresses stay in SGPRs
     const f32x4* bb = P.bl[layer - 1];
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 // covered by the other's MFMAs.  The last layer keeps UT = 4: its 64 units are one head chunk (with TG = 2 the chunk's chain
 // passes from the wave that owns tiles 0-1 to the one that owns tiles 2-3 through LDS).
 template <int HP, bool LAST, int TG, int UT>
-__global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ) {
+__global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
     constexpr int WPG = 4 / TG;            // waves per tree group
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     const int us = m / TQ, tq = m % TQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = us * UT;                          // the UT output tiles
-    const int g0 = tq * TG;                          // the TG tree groups
+    const int g0 = g_base + tq * TG;                 // the TG tree groups
     const int wg = wave % TG, wt0 = (wave / TG) * WT;   // this wave: tree group g0 + wg, tiles t0 + wt0 .. + WT
     const f32x4* W = P.Wl[layer - 1];
     const f32x4* in = L.act[in_buf];

@@ -1,17 +1,24 @@
 // ls_dispatch.cuh -- host-side launch sequence of the lock-step path (included by dispatch_lockstep.hip).
 #pragma once
 #include <cstdlib>
+#include <cstring>
 
 #include "engine_host.h"
 #include "lockstep.cuh"
 
+// The launch sequence of one search.  The batch is cut into e->opt.ls_pipes independent pipelines (ranges of tree-group pairs),
+// pipeline p on stream p: per simulation step a tree kernel (+ first layer) and one kernel per hidden->hidden layer.  The
+// pipelines share nothing but read-only data, so a pipeline's small latency-bound tree kernel runs beside the others' layer
+// kernels.  The whole multi-stream sequence is captured once into a hipGraph and replayed for every search (the search index
+// lives in device memory); it is re-captured when anything it bakes in (kernel parameters, buffers, geometry) changes.
 template <int ENV, int HP, bool GMM>
-static hipError_t ls_run(azg_engine* e) {
+static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
     constexpr int NS = HP / 256, NCH = HP / 64;
     const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG;
     const size_t tab_bytes = ((size_t)e->tab_n * 8 + (size_t)(e->cfg.n_sims + 2) * 4 + 15) / 16 * 16;
     const size_t act_bytes = (size_t)HP * 64;
-    auto tk = ls_tree_kernel<ENV, GMM, NCH>;
+    const bool fuse0 = e->opt.ls_fuse0 != 0;
+    auto tk = fuse0 ? ls_tree_kernel<ENV, GMM, NCH, HP, true> : ls_tree_kernel<ENV, GMM, NCH, HP, false>;
     auto hk = ls_hidden_kernel<HP, false>;
     auto hl = ls_hidden_kernel<HP, true>;
     if (act_bytes > 48 * 1024) {
@@ -23,7 +30,7 @@ static hipError_t ls_run(azg_engine* e) {
     // (32 trees x 64 units per workgroup: two workgroups per CU at 1024 trees x 1024 units)
     auto tkh = ls_hidden_tiled_kernel<HP, false, 2, 4>;
     auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
-    const int TQ = (G + 1) / 2, NU = HP / 64;
+    const int TQ_all = (G + 1) / 2, NU = HP / 64;
     const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
     const bool tiled = e->opt.ls_tiled != 0;
     if (tiled) {
@@ -31,23 +38,74 @@ static hipError_t ls_run(azg_engine* e) {
         if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
         if (rc != hipSuccess) return rc;
     }
-    hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, -2);
-    for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
-        hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(G * NS), dim3(256), 0, e->stream, e->P, e->ls);
-        for (int l = 1; l < e->n_hidden; ++l) {
-            const bool last = l == e->n_hidden - 1;
-            if (tiled) {
-                if (last) hipLaunchKernelGGL(tkl, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
-                else hipLaunchKernelGGL(tkh, dim3(TQ * NU), dim3(256), tiled_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1, TQ);
-            } else if (last) {
-                hipLaunchKernelGGL(hl, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
-            } else {
-                hipLaunchKernelGGL(hk, dim3(G * NS), dim3(256), act_bytes, e->stream, e->P, e->ls, l, (l - 1) & 1);
+    int pipes = e->opt.ls_pipes;
+    if (pipes > TQ_all) pipes = TQ_all;
+    if (pipes > LS_MAX_PIPES) pipes = LS_MAX_PIPES;
+    if (pipes < 1) pipes = 1;
+    // fork: the other pipelines' streams start behind everything already queued on the main stream
+    if (pipes > 1) {
+        hipError_t rc = hipEventRecord(e->ls_fork, main);
+        for (int p = 1; p < pipes && rc == hipSuccess; ++p) rc = hipStreamWaitEvent(e->ls_streams[p], e->ls_fork, 0);
+        if (rc != hipSuccess) return rc;
+    }
+    for (int p = 0; p < pipes; ++p) {
+        hipStream_t st = p == 0 ? main : e->ls_streams[p];
+        const int tq0 = (int)((long)TQ_all * p / pipes), tq1 = (int)((long)TQ_all * (p + 1) / pipes);
+        const int TQ = tq1 - tq0, g_base = 2 * tq0;
+        int Gp = 2 * TQ;                      // tree groups of this pipeline (the last one may end on an odd group)
+        if (g_base + Gp > G) Gp = G - g_base;
+        hipLaunchKernelGGL(tk, dim3(Gp), dim3(256), tab_bytes, st, e->P, e->ls, -2, g_base);
+        for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
+            if (!fuse0) hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(Gp * NS), dim3(256), 0, st, e->P, e->ls, g_base);
+            for (int l = 1; l < e->n_hidden; ++l) {
+                const bool last = l == e->n_hidden - 1;
+                if (tiled) {
+                    if (last) hipLaunchKernelGGL(tkl, dim3(TQ * NU), dim3(256), tiled_bytes, st, e->P, e->ls, l, (l - 1) & 1, TQ, g_base);
+                    else hipLaunchKernelGGL(tkh, dim3(TQ * NU), dim3(256), tiled_bytes, st, e->P, e->ls, l, (l - 1) & 1, TQ, g_base);
+                } else if (last) {
+                    hipLaunchKernelGGL(hl, dim3(Gp * NS), dim3(256), act_bytes, st, e->P, e->ls, l, (l - 1) & 1, g_base);
+                } else {
+                    hipLaunchKernelGGL(hk, dim3(Gp * NS), dim3(256), act_bytes, st, e->P, e->ls, l, (l - 1) & 1, g_base);
+                }
             }
+            hipLaunchKernelGGL(tk, dim3(Gp), dim3(256), tab_bytes, st, e->P, e->ls, sim, g_base);
         }
-        hipLaunchKernelGGL(tk, dim3(G), dim3(256), tab_bytes, e->stream, e->P, e->ls, sim);
+    }
+    // join
+    for (int p = 1; p < pipes; ++p) {
+        hipError_t rc = hipEventRecord(e->ls_join[p], e->ls_streams[p]);
+        if (rc == hipSuccess) rc = hipStreamWaitEvent(main, e->ls_join[p], 0);
+        if (rc != hipSuccess) return rc;
     }
     return hipGetLastError();
+}
+
+template <int ENV, int HP, bool GMM>
+static hipError_t ls_run(azg_engine* e) {
+    // the search index of this launch sequence
+    hipError_t rc = hipMemcpyAsync(e->d_ls_sidx, &e->P.search_idx, sizeof(unsigned), hipMemcpyHostToDevice, e->stream);
+    if (rc != hipSuccess) return rc;
+    if (!e->opt.ls_graph) return ls_enqueue<ENV, HP, GMM>(e, e->stream);
+    // captured graph, keyed by everything the launches bake in
+    KParams key = e->P;
+    key.search_idx = 0;
+    const bool same = e->ls_graph_exec && memcmp(&key, &e->ls_graph_key, sizeof(KParams)) == 0 && e->ls_graph_pipes == e->opt.ls_pipes;
+    if (!same) {
+        if (e->ls_graph_exec) { (void)hipGraphExecDestroy(e->ls_graph_exec); e->ls_graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        rc = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        if (rc != hipSuccess) return rc;
+        hipError_t rq = ls_enqueue<ENV, HP, GMM>(e, e->stream);
+        rc = hipStreamEndCapture(e->stream, &graph);
+        if (rq != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return rq; }
+        if (rc != hipSuccess) return rc;
+        rc = hipGraphInstantiate(&e->ls_graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (rc != hipSuccess) { e->ls_graph_exec = nullptr; return rc; }
+        e->ls_graph_key = key;
+        e->ls_graph_pipes = e->opt.ls_pipes;
+    }
+    return hipGraphLaunch(e->ls_graph_exec, e->stream);
 }
 
 template <int ENV>

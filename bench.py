@@ -75,6 +75,24 @@ def physical_cores():
     return len(seen) or (os.cpu_count() or 1)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by a cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline():
     """CPU lines next to the GPU number, each on a bounded sample of the same workload:
       * the C oracle (scalar port of the per-tree algorithm, OpenMP over trees, trees allocated by their worker thread) on one
@@ -88,7 +106,7 @@ def cpu_baseline():
     from alphazero_gym_amd import _capi
     from alphazero_gym_amd.synthetic import make_weights
 
-    cores = physical_cores()
+    cores = min(physical_cores(), usable_cpus())   # one worker per physical core the process is allowed to run on
     desc = _capi.make_desc(3, HIDDEN, 2, "elu")
     blob = make_weights(34, 3, HIDDEN, 2)
 
@@ -121,7 +139,7 @@ def cpu_baseline():
     dtpy = time.perf_counter() - t0
     return {"value": rall, "unit": "sims/s", "cores": cores, "kind": "port",
             "sample": f"{repsall} searches of {nall} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle, OpenMP over trees on "
-                      f"{cores} threads (one per physical core of {os.cpu_count()} logical CPUs), {dtall:.1f} s",
+                      f"{cores} threads (physical cores {physical_cores()}, usable CPUs {usable_cpus()}, logical CPUs {os.cpu_count()}), {dtall:.1f} s",
             "single_thread": {"value": r1, "unit": "sims/s", "cores": 1, "sample": f"{reps1} searches of {n1} trees x {N_SIMS} sims, {dt1:.1f} s"},
             "python_object_tree": {"value": rpy, "unit": "sims/s", "cores": procs, "kind": "port",
                                    "sample": f"{procs} processes x 2 trees x {N_SIMS} sims, 1 torch thread each, oracle/pytree.py "
