@@ -156,9 +156,9 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.waves = env_digit("AZG_WAVES", 0);
     e->opt.groups = env_digit("AZG_GROUPS", 0);
     e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
-    e->opt.ls_graph = env_digit("AZG_LS_GRAPH", 1);
-    e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 2);
-    e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 1);
+    e->opt.ls_graph = env_digit("AZG_LS_GRAPH", 0);
+    e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
+    e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr; e->d_ls_sidx = nullptr; e->ls_graph_exec = nullptr; e->ls_graph_pipes = 0;
     e->carry_max = 0;

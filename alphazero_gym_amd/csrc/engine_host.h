@@ -17,9 +17,11 @@ struct EngineOptions {
     int waves;                 // AZG_WAVES=4|8 (0: automatic)
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
-    int ls_graph;              // AZG_LS_GRAPH=0: plain launches instead of a captured hipGraph on the lock-step path
-    int ls_pipes;              // AZG_LS_PIPES=n: independent pipelines (streams) the lock-step path cuts the batch into
-    int ls_fuse0;              // AZG_LS_FUSE0=0: the first layer as a launch of its own instead of the tree kernel's tail
+    // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
+    int ls_graph;              // AZG_LS_GRAPH=1: the lock-step launch sequence as a captured hipGraph (same time: not host-bound)
+    int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of
+                               // different queues do not share the chip well)
+    int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256)
 };
 #define LS_MAX_PIPES 8
 

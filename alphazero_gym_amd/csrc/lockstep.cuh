@@ -1,15 +1,17 @@
 // lockstep.cuh -- wide policy/value networks (hidden width >= 512; BASELINE config E: 4x1024): one simulation step = a few
 // grid-wide launches instead of one persistent kernel, so that a network layer of ALL trees is spread over ALL CUs.
-//   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand), then the
-//                      first network layer of the new leaves (K = obs_dim <= 4: one MFMA k-step per tile) straight from the
-//                      observations it holds in LDS; trees and the per-tree state live in global memory between launches
-//   ls_layer0_kernel   first layer for (tree group, 256-unit slice) as a launch of its own (AZG_LS_FUSE0=0, diagnostics)
+//   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand); trees and
+//                      the per-tree state live in global memory between launches.  (AZG_LS_FUSE0=1: also the first network layer
+//                      of the new leaves, from the observations it holds in LDS -- measured slower: 64 workgroups do what 256 did)
+//   ls_layer0_kernel   first layer for (tree group, 256-unit slice)
 //   ls_hidden_tiled_kernel   one hidden->hidden layer as an LDS-tiled GEMM, 32 trees x 64 units per workgroup, both operands
 //                      double-buffered through LDS, two workgroups per CU; the last layer also leaves the partial head sums
 //   ls_hidden_kernel   the earlier form of that layer (16 trees x 256 units, weights streamed from L2 into registers), kept
 //                      behind AZG_LS_TILED=0
 // The arithmetic (MFMA chains, chunked head sums) is the persistent kernel's, bit for bit.
 #pragma once
+#include <type_traits>
+
 #include "records.h"
 #include "env.cuh"
 #include "mlp.cuh"
@@ -195,6 +197,12 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #ifndef LS_KC
 #define LS_KC 4
 #endif
+#ifndef LS_PIPE
+#define LS_PIPE 3        // operand staging schedule of the tiled layer kernel (see there)
+#endif
+#ifndef LS_XCD_2D
+#define LS_XCD_2D 1      // XCD-rectangle block mapping (0: unit slices per XCD)
+#endif
 // Tile shape: TG tree groups x UT unit tiles per workgroup.  4 x 4 (one workgroup per CU at 1024 trees x 1024 units) or half
 // of that -- 4 x 2 or 2 x 4: twice the workgroups, two of them resident per CU, so that one's barrier / LDS-refill bubbles are
 // covered by the other's MFMAs.  The last layer keeps UT = 4: its 64 units are one head chunk (with TG = 2 the chunk's chain
@@ -212,11 +220,22 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     constexpr int NLA = ASZ / 256, NLB = BSZ / 256;       // float4 loads per thread per chunk
     static_assert(ASZ % 256 == 0 && BSZ % 256 == 0, "chunk does not divide over the workgroup");
     extern __shared__ f32x4 s_ab[];                        // two stages
-    // blocks of one XCD (blockIdx % 8) share unit slices: every XCD's L2 holds NU/8 slices' weights
+    // Blocks of one XCD (blockIdx % 8; placement is a speed matter only) work on one rectangle of the output: a quarter of the
+    // unit slices x half of the tree-group pairs, so that the XCD's 4 MB L2 holds both the weights (NU/4 slices) and the
+    // activations (TQ/2 pairs) its blocks share -- 3 MB at 1024 trees x 1024 units; with the earlier mapping (all trees x two
+    // slices per XCD: 4.5 MB) the activations kept falling out to the Infinity Cache.
     const int nb = TQ * NU;
-    int m = blockIdx.x;
-    if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
-    const int us = m / TQ, tq = m % TQ;
+    int us, tq;
+    if (LS_XCD_2D && NU % 4 == 0 && TQ % 2 == 0) {
+        const int x = blockIdx.x % 8, j = blockIdx.x / 8;          // XCD, index within the XCD's share (nb / 8 blocks)
+        const int ub = NU / 4, tb = TQ / 2;                          // rectangle: ub slices x tb pairs
+        us = (x % 4) * ub + j % ub;                                  // neighbours in time share an activation block (j / ub)
+        tq = (x / 4) * tb + j / ub;
+    } else {
+        int m = blockIdx.x;
+        if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
+        us = m / TQ; tq = m % TQ;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = us * UT;                          // the UT output tiles
     const int g0 = g_base + tq * TG;                 // the TG tree groups
@@ -224,37 +243,53 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     const f32x4* W = P.Wl[layer - 1];
     const f32x4* in = L.act[in_buf];
     f32x4 ra[NLA], rb[NLB];
+    // piece j of a chunk's staging: NLA float4 of the weights, then NLB of the activations, per thread
+    auto load_one = [&](int c, int j) {
+        const int jj = j < NLA ? j : j - NLA;
+        const int e = jj * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tile / tree group, offset in its chunk
+        if (j < NLA) ra[jj] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
+        else rb[jj] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
+    };
+    auto store_one = [&](int st, int j) {
+        if (j < NLA) s_ab[st * STAGE + j * 256 + tid] = ra[j];
+        else s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = rb[j - NLA];
+    };
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) {
-            const int e = j * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tile, offset in the tile's chunk
-            ra[j] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
-        }
-#pragma unroll
-        for (int j = 0; j < NLB; ++j) {
-            const int e = j * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tree group, offset in the group's chunk
-            rb[j] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
-        }
+        for (int j = 0; j < NLA + NLB; ++j) load_one(c, j);
     };
     auto store_chunk = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) s_ab[st * STAGE + j * 256 + tid] = ra[j];
-#pragma unroll
-        for (int j = 0; j < NLB; ++j) s_ab[st * STAGE + ASZ + j * 256 + tid] = rb[j];
+        for (int j = 0; j < NLA + NLB; ++j) store_one(st, j);
     };
     f32x4 acc[WT];   // bias first: store_chunk's wait for the chunk then covers it
 #pragma unroll
     for (int i = 0; i < WT; ++i) acc[i] = P.bl[layer - 1][(t0 + wt0 + i) * 64 + lane];
     load_chunk(0);
     store_chunk(0);
+    if (LS_PIPE >= 2 && NCHUNK > 1) load_chunk(1);
     __syncthreads();
     // the bias has to have arrived before the loop: a wait for it inside the loop would, from the second pass on, wait for the
     // next chunk's loads instead (waitcnt placement is static)
 #pragma unroll
     for (int i = 0; i < WT; ++i) asm volatile("" : "+v"(acc[i]));
-#pragma unroll 1
-    for (int c = 0; c < NCHUNK; ++c) {
-        if (c + 1 < NCHUNK) load_chunk(c + 1);       // in flight under this chunk's MFMAs
+    // Staging schedules (LS_PIPE):
+    //   1  chunk c+1 requested at the top of iteration c, stored to LDS behind the iteration's MFMAs
+    //   2  chunk c+1 (requested an iteration ago) stored at the top of iteration c, chunk c+2 requested right after
+    //   3  like 2, but the stores and requests are dealt out one piece at a time BETWEEN the iteration's MFMA groups: they issue
+    //      in the shadow of the MFMA in flight, so that a wave's stretch without matrix work per chunk shrinks to the barrier.
+    //      (Profile of schedule 1: both workgroups of a CU run in phase, MFMAs together and staging together, and the matrix pipe
+    //      idles for the whole staging stretch: 3.1k cycles per chunk for 2k cycles of MFMA.)
+    constexpr int NL = NLA + NLB, NGRP = 4 * KC;          // staging pieces, MFMA groups per chunk
+    constexpr int SLOT0 = 1, SLOTD = (NGRP - 2) / NL > 0 ? (NGRP - 2) / NL : 1;   // piece j goes behind MFMA group SLOT0 + j * SLOTD
+    // one chunk: HAS1 / HAS2 = chunks c+1 / c+2 exist (compile-time, so that the loop body has no branches: the wait counts in
+    // front of the stores then name exactly the loads they need, not "everything in flight")
+    auto chunk = [&](int c, auto has1_t, auto has2_t) {
+        constexpr bool has1 = decltype(has1_t)::value, has2 = decltype(has2_t)::value;
+        if (LS_PIPE == 2) {
+            if (has1) store_chunk((c + 1) & 1);
+            if (has2) load_chunk(c + 2);
+        } else if (LS_PIPE == 1 && has1) load_chunk(c + 1);       // in flight under this chunk's MFMAs
         const f32x4* sB = s_ab + (c & 1) * STAGE + ASZ + wg * KC * 64;
         const f32x4* sA = s_ab + (c & 1) * STAGE + wt0 * KC * 64;
         // operands of k-block s+1 are read from LDS while the MFMAs of k-block s run
@@ -271,22 +306,34 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b.x, acc[i], 0, 0, 0);
+            for (int cmp = 0; cmp < 4; ++cmp) {
 #pragma unroll
-            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b.y, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b.z, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b.w, acc[i], 0, 0, 0);
+                for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cmp], b[cmp], acc[i], 0, 0, 0);
+                if (LS_PIPE == 3) {
+                    const int q = 4 * s + cmp;
+                    if (q >= SLOT0 && (q - SLOT0) % SLOTD == 0 && (q - SLOT0) / SLOTD < NL) {
+                        const int j = (q - SLOT0) / SLOTD;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (has1) store_one((c + 1) & 1, j);
+                        if (has2) load_one(c + 2, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             if (s + 1 < KC) {
                 b = bn;
 #pragma unroll
                 for (int i = 0; i < WT; ++i) a[i] = an[i];
             }
         }
-        if (c + 1 < NCHUNK) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
+        if (LS_PIPE == 1 && has1) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
         __syncthreads();
-    }
+    };
+    static_assert(NCHUNK >= 2, "the staging pipeline is written for at least two chunks");
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK - 2; ++c) chunk(c, std::true_type{}, std::true_type{});
+    chunk(NCHUNK - 2, std::true_type{}, std::false_type{});
+    chunk(NCHUNK - 1, std::false_type{}, std::false_type{});
     f32x4 h[WT];
 #pragma unroll
     for (int i = 0; i < WT; ++i) h[i] = act4<true>(P.act, acc[i]);
