@@ -92,7 +92,7 @@ static int ls_prepare(azg_engine* e) {
     e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts;
     e->ls.tree = tr; e->ls.lane = ln; e->ls.search_idx = e->d_ls_sidx;
     // the padding groups are computed like the others (their columns never mix with real ones): give them defined inputs
-    if (hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
+    if (hipMemset(obsT, 0, G * 64 * sizeof(float)) != hipSuccess || hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
     e->ls_hp = e->HP;
     return AZG_OK;
 }

@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 // of that -- 4 x 2 or 2 x 4: twice the workgroups, two of them resident per CU, so that one's barrier / LDS-refill bubbles are
 // covered by the other's MFMAs.  The last layer keeps UT = 4: its 64 units are one head chunk (with TG = 2 the chunk's chain
 // passes from the wave that owns tiles 0-1 to the one that owns tiles 2-3 through LDS).
-template <int HP, bool LAST, int TG, int UT>
+// L0IN (first hidden->hidden layer only): the B operand is not read from memory but made here -- the first network layer
+// (K = obs_dim <= 4: one MFMA k-step per tile, then the activation) of this chunk's 4 input tiles for the block's tree groups,
+// computed straight into the B stage in the slots where the other layers store their loaded activations.  It saves the
+// first-layer kernel at the price of every unit slice recomputing those tiles (as a launch of its own it measured slightly
+// slower than the separate first-layer kernel; the team kernel uses it because it saves a hand-off).
+template <int HP, bool LAST, int TG, int UT, bool L0IN = false>
 __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
@@ -243,15 +248,31 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     const f32x4* W = P.Wl[layer - 1];
     const f32x4* in = L.act[in_buf];
     f32x4 ra[NLA], rb[NLB];
+    // L0IN: B piece jj is tree group jj, and in it this wave's entry is input tile c * KC + wave (KC * 64 == 256 threads):
+    // first-layer weights of that tile (one per chunk, for both groups) and the groups' observations (once)
+    static_assert(!L0IN || (NLB == TG && KC * 64 == 256), "L0IN: one B piece per tree group, one k-block per wave");
+    float w0r = 0.0f, bo[TG];
+    f32x4 b0r = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (L0IN) {
+#pragma unroll
+        for (int i = 0; i < TG; ++i) bo[i] = L.obsT[(size_t)(g0 + i) * 64 + lane];
+    }
     // piece j of a chunk's staging: NLA float4 of the weights, then NLB of the activations, per thread
     auto load_one = [&](int c, int j) {
         const int jj = j < NLA ? j : j - NLA;
         const int e = jj * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tile / tree group, offset in its chunk
         if (j < NLA) ra[jj] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
-        else rb[jj] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
+        else if constexpr (L0IN) {
+            if (jj == NLB - 1) {   // behind the chunk's last B store: the registers are free for the next chunk's tile
+                w0r = P.W0[(c * KC + wave) * 64 + lane];
+                b0r = P.b0[(c * KC + wave) * 64 + lane];
+            }
+        } else rb[jj] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
     };
     auto store_one = [&](int st, int j) {
         if (j < NLA) s_ab[st * STAGE + j * 256 + tid] = ra[j];
+        else if constexpr (L0IN)
+            s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = act4<true>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(w0r, bo[j - NLA], b0r, 0, 0, 0));
         else s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = rb[j - NLA];
     };
     auto load_chunk = [&](int c) {

@@ -17,7 +17,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 NS = 200
 flop = 2 * (3 * 1024 + 3 * 1024 * 1024 + 1024 * 3)
 ref = None
-for pipes, graph, fuse in [(1, 0, 0), (1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 1), (3, 1, 1), (4, 1, 1), (8, 1, 1)]:
+for pipes, graph, fuse in [(1, 0, 0), (1, 0, 2), (1, 0, 0), (1, 0, 2), (1, 0, 1)]:
     os.environ.update(AZG_LS_PIPES=str(pipes), AZG_LS_GRAPH=str(graph), AZG_LS_FUSE0=str(fuse))
     e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), make_weights(34, 3, [1024] * 4, 2))
