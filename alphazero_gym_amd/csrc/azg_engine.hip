@@ -72,7 +72,6 @@ static int dalloc(azg_engine* e, T** p, size_t n, std::vector<void*>& reg) {
 // ---- lock-step path (wide networks): a few grid-wide launches per simulation step
 static int ls_prepare(azg_engine* e) {
     if (e->ls_hp == e->HP) return AZG_OK;
-    if (e->ls_graph_exec) { (void)hipGraphExecDestroy(e->ls_graph_exec); e->ls_graph_exec = nullptr; }
     for (void* p : e->ls_allocs) (void)hipFree(p);
     e->ls_allocs.clear();
     if (!e->ls_fork) {
@@ -85,12 +84,14 @@ static int ls_prepare(azg_engine* e) {
     // tree groups padded to a multiple of 4: the tiled layer kernel works on 4 groups per workgroup
     const size_t B = e->cfg.n_trees, G = ((B + TREES_PER_WG - 1) / TREES_PER_WG + 3) / 4 * 4, HP = e->HP;
     float* obsT; float *a0, *a1, *parts; LsTree* tr; LsLane* ln;
-    if (dalloc(e, &e->d_ls_sidx, (size_t)4, e->ls_allocs) || dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
+    e->team_cnt_bytes = (((B + 31) / 32) * 8 * 32 + 32) * sizeof(unsigned);   // per team 8 counters 128 B apart, + the abort word
+    if (dalloc(e, &e->d_team_cnt, e->team_cnt_bytes / 4, e->ls_allocs) ||
+        dalloc(e, &obsT, G * 64, e->ls_allocs) || dalloc(e, &a0, G * HP * 16, e->ls_allocs) || dalloc(e, &a1, G * HP * 16, e->ls_allocs) ||
         dalloc(e, &parts, G * (HP / 64) * 64 * 4, e->ls_allocs) || dalloc(e, &tr, B, e->ls_allocs) ||
         dalloc(e, &ln, B * 16, e->ls_allocs))
         return AZG_E_DEVICE;
     e->ls.obsT = obsT; e->ls.act[0] = (f32x4*)a0; e->ls.act[1] = (f32x4*)a1; e->ls.parts = (f32x4*)parts;
-    e->ls.tree = tr; e->ls.lane = ln; e->ls.search_idx = e->d_ls_sidx;
+    e->ls.tree = tr; e->ls.lane = ln;
     // the padding groups are computed like the others (their columns never mix with real ones): give them defined inputs
     if (hipMemset(obsT, 0, G * 64 * sizeof(float)) != hipSuccess || hipMemset(a0, 0, G * HP * 16 * sizeof(float)) != hipSuccess || hipMemset(a1, 0, G * HP * 16 * sizeof(float)) != hipSuccess) return AZG_E_DEVICE;
     e->ls_hp = e->HP;
@@ -105,6 +106,23 @@ static int env_digit(const char* name, int dflt) {
 static bool use_lockstep(const azg_engine* e) {
     if (e->opt.force_persistent) return false;
     return e->HP >= 512 && e->n_hidden >= 2 && !e->P.layernorm;
+}
+
+// The persistent team kernel leaves instead of hanging when one of its waits times out (workgroups not co-resident): it raises
+// a word that is read here, after the stream has been synchronised.  From then on the engine uses the per-layer launches.
+static int team_check(azg_engine* e) {
+    if (!e->team_pending) return AZG_OK;
+    e->team_pending = 0;
+    unsigned flag = 0;
+    if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
+    if (flag != 0) {
+        e->opt.ls_team = 0;
+        e->searched = 0;
+        return fail(e, AZG_E_DEVICE, "the persistent team kernel timed out (its workgroups were not all resident); the engine now uses "
+                                     "the per-layer launches: search again");
+    }
+    return AZG_OK;
 }
 
 extern "C" {
@@ -123,7 +141,6 @@ void azg_engine_destroy(azg_engine* e) {
     if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
-    if (e->ls_graph_exec) (void)hipGraphExecDestroy(e->ls_graph_exec);
     for (int p = 0; p < LS_MAX_PIPES; ++p) {
         if (e->ls_streams[p]) (void)hipStreamDestroy(e->ls_streams[p]);
         if (e->ls_join[p]) (void)hipEventDestroy(e->ls_join[p]);
@@ -156,11 +173,12 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.waves = env_digit("AZG_WAVES", 0);
     e->opt.groups = env_digit("AZG_GROUPS", 0);
     e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
-    e->opt.ls_graph = env_digit("AZG_LS_GRAPH", 0);
     e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
+    e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
+    e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->ls_team_lds = 0; e->team_pending = 0;
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
-    e->ls_fork = nullptr; e->d_ls_sidx = nullptr; e->ls_graph_exec = nullptr; e->ls_graph_pipes = 0;
+    e->ls_fork = nullptr;
     e->carry_max = 0;
     e->d_wblob = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
     e->d_eval = nullptr; e->eval_floats = 0;
@@ -473,7 +491,7 @@ int azg_sync(azg_engine* e) {
     if (!e) return AZG_E_INVALID;
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    return AZG_OK;
+    return team_check(e);
 }
 
 int azg_search(azg_engine* e, const double* roots, const int32_t* carry) {
@@ -497,6 +515,11 @@ static int gather_results(azg_engine* e) {
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     if (e->results_valid) return AZG_OK;
     ON_DEVICE(e);
+    if (e->team_pending) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int trc = team_check(e);
+        if (trc) return trc;
+    }
     int B = e->cfg.n_trees;
     hipLaunchKernelGGL(results_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
                        e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
@@ -576,6 +599,7 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    { int trc = team_check(e); if (trc) return trc; }
     size_t B = e->cfg.n_trees, R = e->R;
     std::vector<RecL> hot(B * R);
     std::vector<Cold> cold(B * R);

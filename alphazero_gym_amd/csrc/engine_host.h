@@ -18,10 +18,11 @@ struct EngineOptions {
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
     // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
-    int ls_graph;              // AZG_LS_GRAPH=1: the lock-step launch sequence as a captured hipGraph (same time: not host-bound)
     int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of
                                // different queues do not share the chip well)
-    int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256)
+    int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256);
+                               // 2: made inside the first hidden layer's staging (+1 %)
+    int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
 };
 #define LS_MAX_PIPES 8
 
@@ -59,10 +60,8 @@ struct azg_engine {
     std::vector<void*> sp_allocs;
     hipStream_t ls_streams[LS_MAX_PIPES];   // [0] unused (the engine's stream)
     hipEvent_t ls_fork, ls_join[LS_MAX_PIPES];
-    unsigned* d_ls_sidx;
-    hipGraphExec_t ls_graph_exec;
-    KParams ls_graph_key;
-    int ls_graph_pipes;
+    unsigned* d_team_cnt; size_t team_cnt_bytes, ls_team_lds;   // team kernel: hand-off counters + abort word
+    int team_pending;        // a team kernel has been launched since its abort word was last read
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;

@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     const int tl = wave * 4 + (lane >> 4);
     const int tg = g_base + blockIdx.x;
-    P.search_idx = *L.search_idx;       // kept in device memory so that a captured launch graph can be replayed for any search
     const int tree = tg * TREES_PER_WG + tl;
     const bool live = tree < P.B;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
@@ -207,13 +206,45 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 // of that -- 4 x 2 or 2 x 4: twice the workgroups, two of them resident per CU, so that one's barrier / LDS-refill bubbles are
 // covered by the other's MFMAs.  The last layer keeps UT = 4: its 64 units are one head chunk (with TG = 2 the chunk's chain
 // passes from the wave that owns tiles 0-1 to the one that owns tiles 2-3 through LDS).
+// Memory access of the tile routine.  Launched as a kernel per layer (SC1 = false) it uses plain loads and stores: the kernel
+// boundary makes the previous layer's output visible.  Inside the persistent team kernel (SC1 = true) the activations, the
+// observations and the head partials are handed from workgroup to workgroup WITHIN the launch: every such byte is stored and
+// loaded with the sc1 bit (write-through past the L2, loads around the per-CU vector L1, which another CU's stores never
+// refresh), as buffer instructions so that the compiler keeps counting them in vmcnt.
+template <bool SC1>
+struct TileMem {
+    __amdgpu_buffer_rsrc_t r;
+    const f32x4* p;
+    __device__ __forceinline__ explicit TileMem(const void* base) : p((const f32x4*)base) {
+        if constexpr (SC1) r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    }
+    __device__ __forceinline__ f32x4 load4(size_t i) const {   // float4 element i
+        if constexpr (SC1) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 16), 0, 16);
+            return __builtin_bit_cast(f32x4, v);
+        } else return p[i];
+    }
+    __device__ __forceinline__ float load1(size_t i) const {   // float element i
+        if constexpr (SC1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4), 0, 16));
+        else return ((const float*)p)[i];
+    }
+    __device__ __forceinline__ void store4(size_t i, f32x4 v) const {
+        if constexpr (SC1) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(i * 16), 0, 16);
+        } else ((f32x4*)p)[i] = v;
+    }
+};
+
 // L0IN (first hidden->hidden layer only): the B operand is not read from memory but made here -- the first network layer
 // (K = obs_dim <= 4: one MFMA k-step per tile, then the activation) of this chunk's 4 input tiles for the block's tree groups,
 // computed straight into the B stage in the slots where the other layers store their loaded activations.  It saves the
 // first-layer kernel at the price of every unit slice recomputing those tiles (as a launch of its own it measured slightly
 // slower than the separate first-layer kernel; the team kernel uses it because it saves a hand-off).
-template <int HP, bool LAST, int TG, int UT, bool L0IN = false>
-__global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {
+// One output tile of a hidden->hidden layer: TG tree groups (from g0) x UT unit tiles (slice us), by one 256-thread workgroup.
+template <int HP, bool LAST, int TG, int UT, bool L0IN, bool SC1>
+__device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
     constexpr int WPG = 4 / TG;            // waves per tree group
@@ -224,29 +255,11 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     constexpr int STAGE = ASZ + BSZ;
     constexpr int NLA = ASZ / 256, NLB = BSZ / 256;       // float4 loads per thread per chunk
     static_assert(ASZ % 256 == 0 && BSZ % 256 == 0, "chunk does not divide over the workgroup");
-    extern __shared__ f32x4 s_ab[];                        // two stages
-    // Blocks of one XCD (blockIdx % 8; placement is a speed matter only) work on one rectangle of the output: a quarter of the
-    // unit slices x half of the tree-group pairs, so that the XCD's 4 MB L2 holds both the weights (NU/4 slices) and the
-    // activations (TQ/2 pairs) its blocks share -- 3 MB at 1024 trees x 1024 units; with the earlier mapping (all trees x two
-    // slices per XCD: 4.5 MB) the activations kept falling out to the Infinity Cache.
-    const int nb = TQ * NU;
-    int us, tq;
-    if (LS_XCD_2D && NU % 4 == 0 && TQ % 2 == 0) {
-        const int x = blockIdx.x % 8, j = blockIdx.x / 8;          // XCD, index within the XCD's share (nb / 8 blocks)
-        const int ub = NU / 4, tb = TQ / 2;                          // rectangle: ub slices x tb pairs
-        us = (x % 4) * ub + j % ub;                                  // neighbours in time share an activation block (j / ub)
-        tq = (x / 4) * tb + j / ub;
-    } else {
-        int m = blockIdx.x;
-        if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
-        us = m / TQ; tq = m % TQ;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = us * UT;                          // the UT output tiles
-    const int g0 = g_base + tq * TG;                 // the TG tree groups
     const int wg = wave % TG, wt0 = (wave / TG) * WT;   // this wave: tree group g0 + wg, tiles t0 + wt0 .. + WT
     const f32x4* W = P.Wl[layer - 1];
-    const f32x4* in = L.act[in_buf];
+    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1]), parts(L.parts), obs(L.obsT);
     f32x4 ra[NLA], rb[NLB];
     // L0IN: B piece jj is tree group jj, and in it this wave's entry is input tile c * KC + wave (KC * 64 == 256 threads):
     // first-layer weights of that tile (one per chunk, for both groups) and the groups' observations (once)
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     f32x4 b0r = {0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (L0IN) {
 #pragma unroll
-        for (int i = 0; i < TG; ++i) bo[i] = L.obsT[(size_t)(g0 + i) * 64 + lane];
+        for (int i = 0; i < TG; ++i) bo[i] = obs.load1((size_t)(g0 + i) * 64 + lane);
     }
     // piece j of a chunk's staging: NLA float4 of the weights, then NLB of the activations, per thread
     auto load_one = [&](int c, int j) {
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
                 w0r = P.W0[(c * KC + wave) * 64 + lane];
                 b0r = P.b0[(c * KC + wave) * 64 + lane];
             }
-        } else rb[jj] = in[((size_t)(g0 + i) * S4 + c * KC) * 64 + r];
+        } else rb[jj] = in.load4(((size_t)(g0 + i) * S4 + c * KC) * 64 + r);
     };
     auto store_one = [&](int st, int j) {
         if (j < NLA) s_ab[st * STAGE + j * 256 + tid] = ra[j];
@@ -360,9 +373,8 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
     for (int i = 0; i < WT; ++i) h[i] = act4<true>(P.act, acc[i]);
     const int tg = g0 + wg;
     if constexpr (!LAST) {
-        f32x4* out = L.act[in_buf ^ 1] + (size_t)tg * S4 * 64;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) out[(t0 + wt0 + i) * 64 + lane] = h[i];
+        for (int i = 0; i < WT; ++i) out.store4(((size_t)tg * S4 + t0 + wt0 + i) * 64 + lane, h[i]);
     } else {
         // the slice's 64 units are one head chunk (chunk index = us): a chain from 0 over its 4 tiles, in tile order
         f32x4 hs = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -379,12 +391,36 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
                 hs = s_ab[wg * 64 + lane];
 #pragma unroll
                 for (int i = 0; i < WT; ++i) hs = mfma4(P.Whead[(t0 + wt0 + i) * 64 + lane], h[i], hs);
-                L.parts[((size_t)tg * NU + us) * 64 + lane] = hs;
+                parts.store4(((size_t)tg * NU + us) * 64 + lane, hs);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) hs = mfma4(P.Whead[(t0 + i) * 64 + lane], h[i], hs);
-            L.parts[((size_t)tg * NU + us) * 64 + lane] = hs;
+            parts.store4(((size_t)tg * NU + us) * 64 + lane, hs);
         }
     }
+}
+
+// A hidden->hidden layer as a launch of its own: one tile per workgroup.
+template <int HP, bool LAST, int TG, int UT, bool L0IN = false>
+__global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {
+    constexpr int NU = HP / (16 * UT);
+    extern __shared__ f32x4 s_ab[];                        // two stages
+    // Blocks of one XCD (blockIdx % 8; placement is a speed matter only) work on one rectangle of the output: a quarter of the
+    // unit slices x half of the tree-group pairs, so that the XCD's 4 MB L2 holds both the weights (NU/4 slices) and the
+    // activations (TQ/2 pairs) its blocks share -- 3 MB at 1024 trees x 1024 units; with the earlier mapping (all trees x two
+    // slices per XCD: 4.5 MB) the activations kept falling out to the Infinity Cache.
+    const int nb = TQ * NU;
+    int us, tq;
+    if (LS_XCD_2D && NU % 4 == 0 && TQ % 2 == 0) {
+        const int x = blockIdx.x % 8, j = blockIdx.x / 8;          // XCD, index within the XCD's share (nb / 8 blocks)
+        const int ub = NU / 4, tb = TQ / 2;                          // rectangle: ub slices x tb pairs
+        us = (x % 4) * ub + j % ub;                                  // neighbours in time share an activation block (j / ub)
+        tq = (x / 4) * tb + j / ub;
+    } else {
+        int m = blockIdx.x;
+        if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
+        us = m / TQ; tq = m % TQ;
+    }
+    ls_tile<HP, LAST, TG, UT, L0IN, false>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
 }

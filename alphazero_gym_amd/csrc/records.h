@@ -115,7 +115,6 @@ struct LockStep {
     f32x4* parts;       // [G][HP/64][64]   partial head sums, one per 64-unit chunk
     LsTree* tree;       // [B]
     LsLane* lane;       // [B][16]
-    const unsigned* search_idx;   // the search index of this launch sequence (device memory: the captured graph is replayed)
 };
 
 

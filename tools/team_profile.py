@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the workgroups of the persistent team kernel (config E) spend their cycles (-DAZG_STAMPS build).
+GPU box only:  make -C alphazero_gym_amd/csrc " + os.environ.get("TEAM_LIB", "libazgym_hip_stamp.so") + " && python tools/team_profile.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "" + os.environ.get("TEAM_LIB", "libazgym_hip_stamp.so") + "")
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from alphazero_gym_amd import _capi, _native  # noqa: E402
+from alphazero_gym_amd.synthetic import make_weights  # noqa: E402
+
+B, NS = 1024, 200
+e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), make_weights(34, 3, [1024] * 4, 2))
+e.upload_roots(e.synthetic_roots())
+for _ in range(2):
+    e.search_resident()
+e.sync()
+print("kernel ms", e.last_search_ms())
+rows = (B + 15) // 16 * 4
+buf = np.zeros((rows, 16), np.uint64)
+lib = _native.lib()
+lib.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+assert lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows) == rows
+w = buf.reshape(-1, 8).astype(np.float64) / (NS + 1)     # [workgroup = team * 16 + slice][slot], cycles per step
+names = ["wait for observations", "tile layer 1 (+ layer 0)", "tile layer 2", "tile layer 3", "arrive + wait between layers",
+         "wait for the last layer", "tree phases", "whole loop"]
+tree = np.zeros(len(w), bool)
+tree[0::16] = True
+tree[1::16] = True
+for kind, m in (("tree workgroups", tree), ("other workgroups", ~tree)):
+    print(kind)
+    for i, nm in enumerate(names):
+        v = w[m, i]
+        print(f"  {nm:30s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles/step")
+print("per step at 2.4 GHz:", w[:, 7].mean() / 2400, "us")
