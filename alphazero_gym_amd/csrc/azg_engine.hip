@@ -176,7 +176,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
-    e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->ls_team_lds = 0; e->team_pending = 0;
+    { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
+    e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0;
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr;
     e->carry_max = 0;
@@ -352,6 +353,11 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
             st[oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
             for (int r = 0; r < 4; ++r) st[ob0 + ((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
         }
+    const size_t oW0u = reserve((size_t)HP * 4), ob0u = reserve((size_t)HP);
+    for (int u = 0; u < HP; ++u) {
+        for (int kk = 0; kk < 4; ++kk) st[oW0u + (size_t)u * 4 + kk] = Wd[0][(size_t)u * 4 + kk];
+        st[ob0u + u] = bd[0][u];
+    }
     size_t oWl[MAX_STREAM_LAYERS] = {0}, obl[MAX_STREAM_LAYERS] = {0};
     for (int l = 1; l < d->n_hidden; ++l) {
         const size_t oW = reserve((size_t)NT * S4 * 64 * 4), ob = reserve((size_t)NT * 64 * 4);
@@ -397,6 +403,8 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     }
     HIPCHK(e, hipMemcpy(e->d_wblob, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* wb = e->d_wblob;
+    e->P.W0u = (const f32x4*)(wb + oW0u);
+    e->P.b0u = (const f32x4*)(wb + ob0u);
     e->P.W0 = wb + oW0;
     e->P.b0 = (const f32x4*)(wb + ob0);
     for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {

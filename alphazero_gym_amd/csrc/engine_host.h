@@ -23,6 +23,7 @@ struct EngineOptions {
     int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256);
                                // 2: made inside the first hidden layer's staging (+1 %)
     int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
+    long team_spin_limit;      // AZG_TEAM_SPIN_LIMIT=n: polls a team hand-off may wait before the launch gives up (tests: 0)
 };
 #define LS_MAX_PIPES 8
 
@@ -60,7 +61,7 @@ struct azg_engine {
     std::vector<void*> sp_allocs;
     hipStream_t ls_streams[LS_MAX_PIPES];   // [0] unused (the engine's stream)
     hipEvent_t ls_fork, ls_join[LS_MAX_PIPES];
-    unsigned* d_team_cnt; size_t team_cnt_bytes, ls_team_lds;   // team kernel: hand-off counters + abort word
+    unsigned* d_team_cnt; size_t team_cnt_bytes;   // team kernel: hand-off counters + abort word
     int team_pending;        // a team kernel has been launched since its abort word was last read
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
@@ -77,5 +78,8 @@ hipError_t azg_dispatch_pendulum_small(azg_engine* e);   // hidden width (padded
 hipError_t azg_dispatch_pendulum_large(azg_engine* e);   // 256 and wider
 hipError_t azg_ls_dispatch_cartpole(azg_engine* e);      // lock-step path (lockstep.cuh), buffers prepared by the caller
 hipError_t azg_ls_dispatch_pendulum(azg_engine* e);
+// the same search as ONE persistent launch (team.cuh); hipErrorNotReady: its workgroups cannot all be resident, use the launches
+hipError_t azg_team_dispatch_cartpole(azg_engine* e);
+hipError_t azg_team_dispatch_pendulum(azg_engine* e);
 // batched network inference of n observations (device pointers) on e->stream (mlp_eval.cuh)
 hipError_t azg_dispatch_mlp_eval(azg_engine* e, const float* obs, int n, float* value, float* dist, float* raw);

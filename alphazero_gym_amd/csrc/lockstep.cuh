@@ -211,11 +211,14 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 // observations and the head partials are handed from workgroup to workgroup WITHIN the launch: every such byte is stored and
 // loaded with the sc1 bit (write-through past the L2, loads around the per-CU vector L1, which another CU's stores never
 // refresh), as buffer instructions so that the compiler keeps counting them in vmcnt.
+// (wt = false: the stores stay plain -- they still write through the L1 to the XCD's L2, where a reader on the SAME XCD finds
+// them with its sc1 loads; the team kernel uses that once it has verified at run time that its team sits on one XCD.)
 template <bool SC1>
 struct TileMem {
     __amdgpu_buffer_rsrc_t r;
     const f32x4* p;
-    __device__ __forceinline__ explicit TileMem(const void* base) : p((const f32x4*)base) {
+    bool wt;
+    __device__ __forceinline__ explicit TileMem(const void* base, bool write_through = true) : p((const f32x4*)base), wt(write_through) {
         if constexpr (SC1) r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     }
     __device__ __forceinline__ f32x4 load4(size_t i) const {   // float4 element i
@@ -232,7 +235,8 @@ struct TileMem {
     __device__ __forceinline__ void store4(size_t i, f32x4 v) const {
         if constexpr (SC1) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(i * 16), 0, 16);
+            if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(i * 16), 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(i * 16), 0, 0);
         } else ((f32x4*)p)[i] = v;
     }
 };
@@ -244,7 +248,7 @@ struct TileMem {
 // slower than the separate first-layer kernel; the team kernel uses it because it saves a hand-off).
 // One output tile of a hidden->hidden layer: TG tree groups (from g0) x UT unit tiles (slice us), by one 256-thread workgroup.
 template <int HP, bool LAST, int TG, int UT, bool L0IN, bool SC1>
-__device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab) {
+__device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab, bool wt = true) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
     constexpr int WPG = 4 / TG;            // waves per tree group
@@ -259,7 +263,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     const int t0 = us * UT;                          // the UT output tiles
     const int wg = wave % TG, wt0 = (wave / TG) * WT;   // this wave: tree group g0 + wg, tiles t0 + wt0 .. + WT
     const f32x4* W = P.Wl[layer - 1];
-    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1]), parts(L.parts), obs(L.obsT);
+    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1], wt), parts(L.parts, wt), obs(L.obsT);
     f32x4 ra[NLA], rb[NLB];
     // L0IN: B piece jj is tree group jj, and in it this wave's entry is input tile c * KC + wave (KC * 64 == 256 threads):
     // first-layer weights of that tile (one per chunk, for both groups) and the groups' observations (once)

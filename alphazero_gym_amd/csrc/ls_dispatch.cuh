@@ -6,7 +6,6 @@
 
 #include "engine_host.h"
 #include "lockstep.cuh"
-#include "team.cuh"
 
 // The launch sequence of one search.  The batch is cut into e->opt.ls_pipes independent pipelines (ranges of tree-group pairs),
 // pipeline p on stream p: per simulation step a tree kernel (+ first layer) and one kernel per hidden->hidden layer.  The
@@ -87,43 +86,10 @@ static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
     return hipGetLastError();
 }
 
-// The persistent team kernel (team.cuh) when every workgroup of its grid can be resident at once; hipErrorNotReady: not here.
-template <int ENV, int HP, bool GMM>
-static hipError_t ls_team_run(azg_engine* e) {
-    constexpr int NU = HP / 64;
-    if (e->n_hidden - 1 >= TEAM_CNT_L0) return hipErrorNotReady;
-    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
-    const size_t lds = (size_t)LS_TILE_STAGE_F4 * 16 + (size_t)e->tab_n * 8 + (size_t)(e->cfg.n_sims + 2) * 4;
-    auto kern = ls_team_kernel<ENV, HP, GMM>;
-    static std::atomic<int> per_cu_cache{-1};
-    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
-    if (per_cu < 0 || lds != e->ls_team_lds) {
-        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (rc != hipSuccess) return rc;
-        rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds);
-        if (rc != hipSuccess) return rc;
-        per_cu_cache.store(per_cu, std::memory_order_relaxed);
-        e->ls_team_lds = lds;
-    }
-    // the occupancy query can answer one block per CU too many where the SGPR file is what limits residency; for 256-thread
-    // blocks that limit is floor(800 / (ceil(sgpr / 16) * 16 + 16)) >= 6 whatever the kernel's sgpr count (<= 112): answers
-    // up to 6 are safe to take as they are (and every wait in the kernel is bounded should this ever be wrong)
-    const int usable = per_cu < 6 ? per_cu : 6;
-    if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
-    hipError_t rc = hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream);
-    if (rc != hipSuccess) return rc;
-    TeamCtl T;
-    T.cnt = e->d_team_cnt;
-    T.abort = e->d_team_cnt + (e->team_cnt_bytes / 4 - 1);   // the last word
-    hipLaunchKernelGGL(kern, dim3(TQ * NU), dim3(256), lds, e->stream, e->P, e->ls, T, TQ);
-    e->team_pending = 1;
-    return hipGetLastError();
-}
-
 template <int ENV, int HP, bool GMM>
 static hipError_t ls_run(azg_engine* e) {
     if (e->opt.ls_team) {
-        hipError_t rc = ls_team_run<ENV, HP, GMM>(e);
+        hipError_t rc = ENV == AZG_ENV_CARTPOLE ? azg_team_dispatch_cartpole(e) : azg_team_dispatch_pendulum(e);
         if (rc != hipErrorNotReady) return rc;
     }
     return ls_enqueue<ENV, HP, GMM>(e, e->stream);

@@ -92,6 +92,8 @@ struct KParams {
     int* n_rec;              // [B]
     const int* pw_need;      // [n_sims+2]
     const double* sqrt_tab;  // [tab_n]  sqrt(n+1)
+    const f32x4* W0u;        // [HP] first layer per unit: (w[u][0], w[u][1], w[u][2], w[u][3]) -- the VALU form of the first layer
+    const f32x4* b0u;        // [HP/4] first-layer bias, four consecutive units per entry
     const float* W0;         // [HP/16][64]
     const f32x4* b0;         // [HP/16][64]
     const f32x4* Wl[MAX_STREAM_LAYERS]; // hidden->hidden layer l (1-based index l-1): [HP/16 tiles][HP/16 s4][64]

@@ -2,46 +2,60 @@
 //
 // The lock-step path (lockstep.cuh) pays five kernel boundaries per simulation step and runs its small, latency-bound tree
 // kernel (64 workgroups) while the other 192 CUs wait.  Here the batch is cut into TEAMS: 32 trees (two 16-tree groups) and the
-// HP/64 workgroups that compute the 64-unit slices of every hidden layer for exactly those trees.  A team never needs data of
-// another team, so nothing in the launch is grid-wide: per simulation step a team goes
-//     tree phases (its first two workgroups, one per tree group)  ->  hidden layer 1 .. n  (all of its workgroups, one tile each)
-// and hands its data from workgroup to workgroup through global memory with one monotonic counter per hand-off (arrive = one
-// atomic add per workgroup, wait = one lane polling).  Teams drift apart in time; a CU hosts two workgroups of different teams
-// (grid = 2 x CUs at config E), so one team's tree phases and hand-off latencies run under the other's MFMAs.
+// NU = HP/64 workgroups that compute the 64-unit slices of every layer for exactly those trees.  A team never needs data of
+// another team, so nothing in the launch is grid-wide.  Every workgroup of a team also OWNS 32/NU of the team's trees (2 at
+// HP = 1024) for the whole search -- resident in its LDS when they fit, like the persistent search kernel's -- and walks them
+// with the first lanes of its first wave.  Per simulation step a team goes
+//     tree phases + first layer (every workgroup, its own trees)  ->  hidden layer 1 .. n (every workgroup, one tile each)
+// and hands activations and head partials from workgroup to workgroup through global memory, one monotonic counter per
+// hand-off (arrive = one atomic add per workgroup, wait = one lane polling).
 //
 // Visibility (MI355X: a CU's vector L1 is never refreshed by other CUs' stores, the XCD L2s are not coherent with each other):
-// every handed-off byte -- activations, observations, head partials -- is stored AND loaded with sc1 buffer instructions
-// (TileMem<true>); an arriving workgroup drains its stores (s_waitcnt vmcnt(0) in every wave), meets at its barrier, then one
+// every handed-off byte is stored AND loaded with sc1 buffer instructions (TileMem<true>: write-through past the L2, loads
+// around the L1); an arriving workgroup drains its stores (s_waitcnt vmcnt(0) in every wave), meets at its barrier, then one
 // lane adds to the counter; a waiting workgroup polls with an sc1 load from one lane and releases the others through its
-// barrier.  Placement (blockIdx % 8 = XCD under round-robin dispatch) is used for speed only: a team sits on one XCD.
+// barrier.  Placement (blockIdx % 8 = XCD under round-robin dispatch) is used for speed: a team sits on one XCD, and once the
+// team has SEEN at run time that it does (its workgroups' XCC_IDs), its hand-off stores stay plain -- they write through the L1
+// into that XCD's L2, where the team's sc1 loads find them -- instead of going through to memory.
 // Deadlock: every workgroup of the grid has to be resident; the host checks the occupancy before choosing this path, and every
 // wait is bounded -- on a time-out the launch raises an abort flag, all workgroups leave, and the host falls back.
 // The arithmetic is the lock-step path's (ls_tile, tree_phase_a/b): bit-identical results.
+//
+// Measured at config E (1024 trees, 4x1024, MI355X): 14.4-14.8 ms per search against 15.6-15.9 ms for the per-layer launches;
+// per step (tools/team_profile.py, 161k cycles): the three tiles 108k (two workgroups per CU side by side: 93 % of the matrix
+// pipe's time while they run), hand-off waits 23k, tree phases + first layer 22k.  The two workgroups of a CU (blocks b and
+// b + 256: tools/team_census.py) belong to different teams; shifting one team by half a step or gating it on its partner's
+// progress did not pay (two tiles side by side take 35k cycles, one alone 24k: running them together is the efficient
+// state), nor did making the first layer inside the first hidden layer's staging (+18k cycles per step) or as a team phase
+// of MFMA tiles behind an observation hand-off (same time as the vector-ALU form here, one hand-off more).
 #pragma once
 #include "lockstep.cuh"
 
 #define TEAM_CNT_STRIDE 32      // counters 128 bytes apart
-#define TEAM_MAX_CNT 8          // counter 0: observations of the step ready; counter l: hidden layer l of the step written
-#define TEAM_SPIN_LIMIT (1u << 23)
-#ifndef TEAM_STAGGER
-#define TEAM_STAGGER 9          // x 8128 cycles: start delay of every second team (about half a simulation step at config E)
-#endif
-#ifndef TEAM_L0IN
-#define TEAM_L0IN 0             // 1: first layer made inside the first hidden layer's staging instead of a team phase of its own
-#endif
-#define TEAM_CNT_L0 (TEAM_MAX_CNT - 1)   // the first layer's hand-off counter (hidden layers use 1 .. n_hidden - 1)
-#ifndef TEAM_MAP
-#define TEAM_MAP 0              // 1: consecutive workgroups of an XCD dealt to different teams (census: not how they are placed)
-#endif
-#ifndef TEAM_GATE
-#define TEAM_GATE 1             // the late team of a pair waits for its partner's middle layer before its tree phases
+#define TEAM_MAX_CNT 8          // counter 0: first layer of the step written; l: hidden layer l written
+#define TEAM_CNT_XA (TEAM_MAX_CNT - 1)   // max XCC_ID of the team's workgroups
+#define TEAM_CNT_XB (TEAM_MAX_CNT - 2)   // max (7 - XCC_ID)
+#ifndef TEAM_SAME_XCD
+#define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
 #define LS_TILE_STAGE_F4 (2 * (4 + 2) * LS_KC * 64)   // float4 entries of the tile routine's two stages (TG = 2, UT = 4)
 
 struct TeamCtl {
-    unsigned* cnt;     // [teams][TEAM_MAX_CNT][TEAM_CNT_STRIDE]
-    unsigned* abort;   // != 0: a wait timed out, everybody leaves
+    unsigned* cnt;         // [teams][TEAM_MAX_CNT][TEAM_CNT_STRIDE]
+    unsigned* abort;       // != 0: a wait timed out, everybody leaves
+    unsigned spin_limit;   // polls (about 0.15 us each) a wait may take: 1 << 23 is more than a second
 };
+
+// dynamic LDS of a team workgroup: the tile stages, sqrt_tab, pw_need, then (LDS trees) the workgroup's trees
+__host__ __device__ inline size_t team_tree_bytes(int R, bool cont, int tlds) {
+    if (tlds == TS_GLOBAL) return 0;
+    size_t per = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * (tlds == TS_LDS9 ? 8 : 4) : (size_t)R * 4);
+    return (per + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t team_table_off() { return (size_t)LS_TILE_STAGE_F4 * 16; }
+__host__ __device__ inline size_t team_tree_off(int tab_n, int n_sims) {
+    return (team_table_off() + (size_t)tab_n * 8 + (size_t)(n_sims + 2) * 4 + 15) / 16 * 16;
+}
 
 // all of this workgroup's hand-off stores are on their way: drain, meet, one lane arrives
 __device__ __forceinline__ void team_arrive(unsigned* c) {
@@ -51,14 +65,15 @@ __device__ __forceinline__ void team_arrive(unsigned* c) {
 }
 
 // wait until the counter reaches `target`; false (uniform over the workgroup): aborted
-__device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, unsigned* abort, volatile int* s_ok) {
+__device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, const TeamCtl& T, volatile int* s_ok) {
+    unsigned* abort = T.abort;
     if (threadIdx.x == 0) {
         int ok = 1;
         unsigned spins = 0;
         while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 255u) == 0u) {
-                if (spins > TEAM_SPIN_LIMIT) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((++spins & 15u) == 0u) {
+                if (spins > T.spin_limit) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
             }
         }
@@ -70,163 +85,178 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, un
     return ok;
 }
 
-template <int ENV, int HP, bool GMM>
-__global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
-    constexpr int NU = HP / 64, NCH = HP / 64;
-    extern __shared__ f32x4 s_ab[];     // the tile routine's two stages (between tiles: the group's head partials, tree workgroups),
-                                        // then sqrt_tab [tab_n] and pw_need [n_sims + 2]
-    __shared__ float s_obs[64];         // [4][16] observations of the group's new leaves
-    __shared__ int s_ok;
-    double* s_sqrt = (double*)(s_ab + LS_TILE_STAGE_F4);
-    int* s_pw = (int*)(s_sqrt + P.tab_n);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
-    // team and slice of this workgroup: the NU workgroups of a team have equal blockIdx % 8 (one XCD under round-robin placement)
-    int tq, us;
-    bool late = false;   // this team starts half a step late (see below)
-    int partner = -1;    // the team that shares this team's CUs (late teams)
-    if (TQ % 8 == 0) {
-        const int x = blockIdx.x % 8, j = blockIdx.x / 8, per_x = TQ / 8;   // XCD, index in the XCD's share, teams per XCD
-#if TEAM_MAP == 1
-        // consecutive workgroups of an XCD land on the same CU (depth-first placement): deal them to different teams
-        if (per_x % 2 == 0) {
-            const int slot = j & 1, r = j >> 1;
-            tq = x * per_x + slot * (per_x / 2) + r / NU; us = r % NU;
-            late = slot != 0;
-        } else
-#endif
-        {
-            tq = x * per_x + j / NU; us = j % NU;
-            // workgroups j and j + (share / 2) of an XCD's share are the two residents of one CU (round-robin, breadth first)
-            late = (int)(blockIdx.x / 8) >= (int)(gridDim.x / 16);
-            if (late && per_x % 2 == 0) partner = tq - per_x / 2;
-        }
-    } else { tq = blockIdx.x / NU; us = blockIdx.x % NU; }
-#ifdef TEAM_HALF
-    if (late) return;   // experiment (timing only, half of the trees are not searched): one workgroup per CU
-#endif
-    const int G = (P.B + TREES_PER_WG - 1) / TREES_PER_WG;
-    const int g0 = 2 * tq;                                   // the team's tree groups g0, g0 + 1
-    const int n_tree_wg = G - g0 >= 2 ? 2 : 1;               // (the last team of an odd number of groups has one)
-    const bool tree_wg = us < n_tree_wg;
-    unsigned* cnt = T.cnt + (size_t)tq * TEAM_MAX_CNT * TEAM_CNT_STRIDE;
-    const int n_layers = P.n_hidden - 1;                     // hidden->hidden layers 1 .. n_layers
-
-    // ---- tree workgroups: tables, tree storage, root
-    const int tg = g0 + us;                                  // (tree workgroups) the tree group
-    const int tl = wave * 4 + (lane >> 4);
-    const int tree = tg * TREES_PER_WG + tl;
-    const bool live = tree_wg && tree < P.B;
-    const unsigned gtree = (unsigned)(P.tree_base + tree);
-    const size_t tb = (size_t)(live ? tree : 0) * P.R;
-    Cold* cold = P.cold + tb;
-    double* edge_W = P.edge_W + tb;
-    float* action = P.action + tb;
-    TreeStore<false> ts;
-    ts.hot = P.hot + tb;
-    ts.child = P.child + tb * P.Kp;
-    ts.prior = P.prior + tb;
-    TreeState st = {};
-    const TileMem<true> obs_mem(L.obsT), parts_mem(L.parts);
-    if (tree_wg) {
-#if TEAM_STAGGER > 0
-        // Teams start together and do the same work: left alone they stay in step, all tree phases at once and all layers at
-        // once, and nothing overlaps.  An offset between the two teams that share a set of CUs persists (each runs faster while
-        // the other is in its tree phase), so one of them starts late: with round-robin dispatch the second half of an XCD's
-        // workgroups are the second residents of its CUs (a speed matter only).
-        if (late)
-            for (int i = 0; i < TEAM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-        for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
-        if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
-        if (tid < 64) s_obs[tid] = 0.0f;
-        __syncthreads();
-        tree_init_root<ENV, false>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, s_obs);
-        __syncthreads();
-        if (tid < 16) obs_mem.store4((size_t)tg * 16 + tid, ((const f32x4*)s_obs)[tid]);
-        team_arrive(cnt);
-    }
 #ifdef AZG_STAMPS
-    // diagnostic build: cycles of this workgroup (thread 0's clock) in  0 wait for observations | 1..3 tile of layer 1..3 |
-    // 4 arrive + wait between layers | 5 wait for the last layer (tree workgroups) | 6 tree phases | 7 whole loop
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TSTAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define TADD(slot, a, b) tacc[slot] += (b) - (a)
 #else
 #define TSTAMP(v)
 #define TADD(slot, a, b)
 #endif
+
+template <int ENV, int HP, bool GMM, int TLDS>
+__global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr int NU = HP / 64, NCH = HP / 64;
+    constexpr int TPW = 32 / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
+    static_assert(TPW >= 1 && TPW <= 4, "a team is 32 trees over HP/64 workgroups");
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    extern __shared__ f32x4 s_ab[];     // the tile routine's two stages (between tiles: the head partials of this workgroup's
+                                        // trees), sqrt_tab [tab_n], pw_need [n_sims + 2], (LDS trees) the trees
+    __shared__ float s_obs[32];         // [4 features][TPW] observations of this workgroup's new leaves, zero padded to a line
+    __shared__ int s_ok;
+    double* s_sqrt = (double*)((char*)s_ab + team_table_off());
+    int* s_pw = (int*)(s_sqrt + P.tab_n);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
+    // team and slice of this workgroup: the NU workgroups of a team have equal blockIdx % 8 (one XCD under round-robin placement)
+    int tq, us;
+    if (TQ % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8; tq = x * (TQ / 8) + j / NU; us = j % NU; }
+    else { tq = blockIdx.x / NU; us = blockIdx.x % NU; }
+    const int g0 = 2 * tq;                                   // the team's tree groups g0, g0 + 1
+    unsigned* cnt = T.cnt + (size_t)tq * TEAM_MAX_CNT * TEAM_CNT_STRIDE;
+    const int n_layers = P.n_hidden - 1;                     // hidden->hidden layers 1 .. n_layers
+
+    // ---- this workgroup's trees
+    const int tj = lane >> 4;                                // tree slot of the lane
+    const bool has_tree = wave == 0 && tj < TPW;
+    const int tt = us * TPW + (has_tree ? tj : 0);           // tree within the team: group g0 + tt / 16, column tt % 16
+    const int tree = tq * 32 + tt;
+    const bool live = has_tree && tree < P.B;
+    const unsigned gtree = (unsigned)(P.tree_base + tree);
+    const size_t tb = (size_t)(live ? tree : 0) * P.R;
+    Cold* cold = P.cold + tb;
+    double* edge_W = P.edge_W + tb;
+    float* action = P.action + tb;
+    TreeStore<TLDS> ts;
+    if constexpr (TLDS != TS_GLOBAL) {
+        char* base = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims) + team_tree_bytes(P.R, CONT, TLDS) * (has_tree ? tj : 0);
+        ts.hot = (Rec*)base;
+        ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
+        ts.prior = (float*)(base + (size_t)P.R * 16);
+    } else {
+        ts.hot = (Rec*)(P.hot + tb);
+        ts.child = P.child + tb * P.Kp;
+        ts.prior = P.prior + tb;
+    }
+    TreeState st = {};
+    // Is the whole team on one XCD?  Every workgroup reports its XCC_ID into two zero-initialised words of the team (max of id
+    // and max of 7 - id: they add up to 7 only if all ids are equal) ahead of its first arrival; checked behind the first wait.
+    // Until then, and whenever the answer is no, hand-off stores write through to memory (sc1).
+    bool wt = true;
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
+        __hip_atomic_fetch_max(cnt + TEAM_CNT_XA * TEAM_CNT_STRIDE, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(cnt + TEAM_CNT_XB * TEAM_CNT_STRIDE, 7u - xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const TileMem<true> parts_mem(L.parts);
+    for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
+    if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
+    if (tid < 32) s_obs[tid] = 0.0f;
+    __syncthreads();
+    // The network's first layer of this workgroup's OWN new leaves, all HP units of it, on the vector ALU straight from the
+    // observations in LDS (K = obs_dim <= 4: the same fma chain from the bias over k = 0..3 as the MFMA form, bit for bit), written
+    // into the team's first activation buffer in the hidden layers' B-operand layout: the observations never travel and the
+    // first layer costs no hand-off of its own.  Thread: tree slot tid / (256 / TPW), 8 consecutive units.
+    const TileMem<true> act0(L.act[0], true);
+    auto first_layer = [&](bool wt_now) {
+        constexpr int TPT = 256 / TPW;                       // threads per tree
+        const int j = tid / TPT, u0 = (tid % TPT) * (HP / TPT);
+        static_assert(HP / TPT == 8, "8 units per thread");
+        const int c = us * TPW + j;                          // the tree within the team: group g0 + c / 16, column c % 16
+        const float x0 = s_obs[0 * TPW + j], x1 = s_obs[1 * TPW + j], x2 = s_obs[2 * TPW + j], x3 = s_obs[3 * TPW + j];
+        TileMem<true> out = act0;
+        out.wt = wt_now;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int u = u0 + 4 * h;
+            f32x4 acc = P.b0u[u / 4];
+            const f32x4 wa = P.W0u[u], wb = P.W0u[u + 1], wc = P.W0u[u + 2], wd = P.W0u[u + 3];
+            acc.x = __builtin_fmaf(wa.x, x0, acc.x); acc.x = __builtin_fmaf(wa.y, x1, acc.x); acc.x = __builtin_fmaf(wa.z, x2, acc.x); acc.x = __builtin_fmaf(wa.w, x3, acc.x);
+            acc.y = __builtin_fmaf(wb.x, x0, acc.y); acc.y = __builtin_fmaf(wb.y, x1, acc.y); acc.y = __builtin_fmaf(wb.z, x2, acc.y); acc.y = __builtin_fmaf(wb.w, x3, acc.y);
+            acc.z = __builtin_fmaf(wc.x, x0, acc.z); acc.z = __builtin_fmaf(wc.y, x1, acc.z); acc.z = __builtin_fmaf(wc.z, x2, acc.z); acc.z = __builtin_fmaf(wc.w, x3, acc.z);
+            acc.w = __builtin_fmaf(wd.x, x0, acc.w); acc.w = __builtin_fmaf(wd.y, x1, acc.w); acc.w = __builtin_fmaf(wd.z, x2, acc.w); acc.w = __builtin_fmaf(wd.w, x3, acc.w);
+            // unit u = 16 t + 4 g + r of tree column cc -> float4 ((group * HP/16 + t) * 64 + g * 16 + cc), component r
+            out.store4(((size_t)(g0 + c / 16) * (HP / 16) + u / 16) * 64 + ((u % 16) / 4) * 16 + c % 16, act4<true>(P.act, acc));
+        }
+    };
+    if (has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, ts, cold, edge_W, action, tree, live, sub, tj, gtree, s_obs);
+    __syncthreads();
+    first_layer(true);
+    team_arrive(cnt);
+#ifdef AZG_STAMPS
+    // diagnostic build: cycles of this workgroup (thread 0's clock) in  0 wait for observations | 1..3 tile of layer 1..3 |
+    // 4 arrive + wait between layers | 5 wait for the last layer | 6 tree phases | 7 whole loop
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     TSTAMP(t_begin);
     for (int k = 0; k <= P.n_sims; ++k) {                    // evaluation k follows trace k - 1 (k = 0: the roots)
         const int sim = k - 1;
         TSTAMP(t0);
-        if (!team_wait(cnt, (unsigned)(n_tree_wg * (k + 1)), T.abort, &s_ok)) return;
+        if (!team_wait(cnt, (unsigned)(NU * (k + 1)), T, &s_ok)) return;
         TSTAMP(t1);
         TADD(0, t0, t1);
-        // ---- the network's first layer (K = obs_dim <= 4: one MFMA k-step per tile): this workgroup's 4 tiles of it, for
-        // both tree groups, handed to the team like a hidden layer.  (Made inside the first hidden layer's operand staging
-        // instead -- ls_tile's L0IN -- it cost that tile 18k cycles more per step: every slice recomputes all of it.)
-        if (!TEAM_L0IN) {
-            const int tile = us * 4 + wave;
-            const float w0 = P.W0[tile * 64 + lane];
-            const f32x4 b0 = P.b0[tile * 64 + lane];
-            const TileMem<true> act0(L.act[0]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float bo = obs_mem.load1((size_t)(g0 + i) * 64 + lane);
-                act0.store4(((size_t)(g0 + i) * (HP / 16) + tile) * 64 + lane, act4<true>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(w0, bo, b0, 0, 0, 0)));
-            }
-            team_arrive(cnt + TEAM_CNT_L0 * TEAM_CNT_STRIDE);
-            if (!team_wait(cnt + TEAM_CNT_L0 * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T.abort, &s_ok)) return;
+        if (TEAM_SAME_XCD && k == 0) {
+            if (tid == 0)
+                s_ok = __hip_atomic_load(cnt + TEAM_CNT_XA * TEAM_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                       __hip_atomic_load(cnt + TEAM_CNT_XB * TEAM_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7u;
+            __syncthreads();
+            wt = s_ok == 0;
+            __syncthreads();
         }
         // ---- the hidden layers: this workgroup's 64-unit slice of each, for the team's 32 trees
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
-            if (l == n_layers) {
-                if (l == 1 && TEAM_L0IN) ls_tile<HP, true, 2, 4, true, true>(P, L, l, in_buf, us, g0, s_ab);
-                else ls_tile<HP, true, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab);
-            } else {
-                if (l == 1 && TEAM_L0IN) ls_tile<HP, false, 2, 4, true, true>(P, L, l, in_buf, us, g0, s_ab);
-                else ls_tile<HP, false, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab);
-            }
+            if (l == n_layers) ls_tile<HP, true, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile<HP, false, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab, wt);
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
-            if (l < n_layers && !team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T.abort, &s_ok)) return;
+            if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;
             TSTAMP(tc);
             TADD(l < 3 ? l : 3, ta, tb_);
-            TADD(4, tb_, tc);
+            TADD(l < n_layers ? 4 : 5, tb_, tc);
         }
-        if (!tree_wg) continue;
-        // ---- tree phases of this workgroup's group: the evaluated leaves' values, backup, next trace
-        TSTAMP(td);
-#if TEAM_GATE
-        // the late team of a CU-sharing pair starts its tree phases when its partner is in the middle of its layers, so that
-        // each team's tree phases and hand-off waits fall under the other's MFMAs (the partner never waits for this team)
-        if (late && partner >= 0 &&
-            !team_wait(T.cnt + ((size_t)partner * TEAM_MAX_CNT + (n_layers + 1) / 2) * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T.abort, &s_ok)) return;
-#endif
-        if (!team_wait(cnt + n_layers * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T.abort, &s_ok)) return;
+        // ---- tree phases of this workgroup's trees: the evaluated leaves' values, backup, next trace.
+        // Their head partials first (chunk w, output row group q, tree slot j -> s_ab[w * 64 + q * 16 + j]: head_output's layout
+        // with the slot as the column)
         TSTAMP(te);
-        TADD(5, td, te);
-        for (int i = tid; i < NCH * 64; i += 256) s_ab[i] = parts_mem.load4((size_t)tg * NCH * 64 + i);   // the group's head partials
+        for (int i = tid; i < NCH * 4 * TPW; i += 256) {
+            const int w = i / (4 * TPW), q = (i / TPW) % 4, j = i % TPW, c = us * TPW + j;
+            s_ab[w * 64 + q * 16 + j] = parts_mem.load4(((size_t)(g0 + c / 16) * NCH + w) * 64 + q * 16 + c % 16);
+        }
         __syncthreads();
 #ifdef AZG_STAMPS
-        unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic build: discarded here
+        unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (the tree phases' own stamps: discarded here)
 #endif
-        if (live) tree_phase_a<ENV, false, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl, gtree, s_ab, P.bhead);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead);
         st.need_eval = false;
         if (k < P.n_sims) {
             __threadfence_block();
-            if (live) tree_phase_b<ENV, false, GMM>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
+            if (live) tree_phase_b<ENV, TLDS, GMM, TPW>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
             __syncthreads();
-            if (tid < 16) obs_mem.store4((size_t)tg * 16 + tid, ((const f32x4*)s_obs)[tid]);
+            first_layer(wt);
             team_arrive(cnt);
-        } else if (live && sub == 0) {
-            P.n_rec[tree] = st.nrec;
         }
         TSTAMP(tf);
         TADD(6, te, tf);
+    }
+    // ---- the trees as the results kernels read them
+    if (live) {
+        if (sub == 0) P.n_rec[tree] = st.nrec;
+        if constexpr (TLDS != TS_GLOBAL) {
+            RecL* gh = P.hot + tb;
+            for (int j = sub; j < st.nrec; j += 16) {
+                Rec h = ts.hot[j];
+                RecL o;
+                o.Q = h.Q; o.edge_n = h.edge_n; o.node_n = h.node_n; o.parent = (short)h.parent; o.n_child = h.n_child;
+                o.first = CONT ? 0 : h.first; o.flags = h.flags; o.pad = 0;
+                gh[j] = o;
+                if (CONT) {
+                    for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = (unsigned short)ts.child_at(j, h, i, P.Kp);
+                } else {
+                    P.prior[tb + j] = ts.prior[j];
+                }
+            }
+        }
     }
 #ifdef AZG_STAMPS
     TSTAMP(t_end);

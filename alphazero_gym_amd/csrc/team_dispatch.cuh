@@ -1,0 +1,73 @@
+// team_dispatch.cuh -- host-side choice and launch of the persistent team kernel (team.cuh); included by dispatch_team.hip.
+#pragma once
+#include <atomic>
+#include <cstdlib>
+
+#include "engine_host.h"
+#include "team.cuh"
+
+// One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
+template <int ENV, int HP, bool GMM, int TLDS>
+static hipError_t team_launch(azg_engine* e) {
+    constexpr int NU = HP / 64, TPW = 32 / NU;
+    constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
+    if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
+    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
+    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
+    if (lds + 1024 > 160 * 1024) return hipErrorNotReady;
+    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS>;
+    static std::atomic<int> per_cu_cache{-1};
+    static std::atomic<size_t> lds_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
+    if (per_cu < 0 || lds != lds_cache.load(std::memory_order_relaxed)) {
+        hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds);
+        if (rc != hipSuccess) return rc;
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
+        lds_cache.store(lds, std::memory_order_relaxed);
+    }
+    // the occupancy query can answer one block per CU too many where the SGPR file is what limits residency; for 256-thread
+    // blocks that limit is floor(800 / (ceil(sgpr / 16) * 16 + 16)) >= 6 whatever the kernel's sgpr count (<= 112): answers
+    // up to 6 are safe to take as they are (and every wait in the kernel is bounded should this ever be wrong)
+    const int usable = per_cu < 6 ? per_cu : 6;
+    if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
+    hipError_t rc = hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream);
+    if (rc != hipSuccess) return rc;
+    TeamCtl T;
+    T.cnt = e->d_team_cnt;
+    T.abort = e->d_team_cnt + (e->team_cnt_bytes / 4 - 1);   // the last word
+    T.spin_limit = (unsigned)e->opt.team_spin_limit;
+    hipLaunchKernelGGL(kern, dim3(TQ * NU), dim3(256), lds, e->stream, e->P, e->ls, T, TQ);
+    e->team_pending = 1;
+    e->tree_lds = TLDS;
+    e->dyn_lds = lds;
+    return hipGetLastError();
+}
+
+// trees in the workgroups' LDS when they fit (same rule as the persistent search kernel's), else in global memory
+template <int ENV, int HP, bool GMM>
+static hipError_t team_storage(azg_engine* e) {
+    const long nmax = (long)e->carry_max + e->cfg.n_sims + 2;
+    hipError_t rc = hipErrorNotReady;
+    if (e->Kp == 16 && !e->opt.force_global_tree) {
+        if (e->R <= 255 && nmax < 65536) rc = team_launch<ENV, HP, GMM, TS_LDS8>(e);
+        else if (e->R <= 511 && nmax < 2048) rc = team_launch<ENV, HP, GMM, TS_LDS9>(e);
+    }
+    if (rc == hipErrorNotReady) rc = team_launch<ENV, HP, GMM, TS_GLOBAL>(e);
+    return rc;
+}
+
+template <int ENV>
+static hipError_t team_dispatch(azg_engine* e) {
+    const bool gmm = ENV != AZG_ENV_CARTPOLE && e->P.ncomp >= 2;
+    if (e->HP == 512) {
+        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return team_storage<ENV, 512, true>(e); }
+        return team_storage<ENV, 512, false>(e);
+    }
+    if (e->HP == 1024) {
+        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return team_storage<ENV, 1024, true>(e); }
+        return team_storage<ENV, 1024, false>(e);
+    }
+    return hipErrorNotReady;
+}

@@ -122,11 +122,12 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "waves8", "groups2"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
-    instead of LDS, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
+    instead of LDS, for wide networks (default: the persistent team kernel) the one-launch search kernel and the per-layer
+    launches, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
     itself only for batches of more 16-tree groups than CUs)."""
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
@@ -140,10 +141,13 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         if hidden != [256, 256] or ln or ncomp:
             pytest.skip("the 8-wave workgroups exist for 2x256 Normal / 2-action networks")
         monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
-    if variant == "persistent":
+    if variant in ("persistent", "launches"):
         if max(hidden) <= 256:
             pytest.skip("lock-step kernels only exist for hidden widths >= 512")
-        monkeypatch.setenv("AZG_FORCE_PERSISTENT", "1")   # wide networks: the one-launch kernel instead of the lock-step path
+        if variant == "persistent":
+            monkeypatch.setenv("AZG_FORCE_PERSISTENT", "1")   # wide networks: the one-launch kernel instead of the lock-step path
+        else:
+            monkeypatch.setenv("AZG_LS_TEAM", "0")            # the per-layer launches instead of the persistent team kernel
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
     in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else (4, 2)
@@ -278,6 +282,31 @@ def test_config_e_full_size_lockstep(native):
         for k in do:
             np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=k)
     assert ms < 40.0, f"config E search took {ms:.1f} ms (measured 16.6 ms in round 1)"
+
+
+def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
+    """The persistent team kernel's waits are bounded: with a spin limit of zero the launch aborts, the engine reports it and
+    falls back to the per-layer launches, and the next search is complete and identical to a clean engine's."""
+    kw = dict(env_id=2, mode=1, n_trees=64, n_sims=20, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=3)
+    desc = _capi.make_desc(3, [512, 512], 2, "elu")
+    blob = O.make_weights(5, 3, [512, 512], 2)
+    good = native.HipEngine(**kw)
+    good.set_weights(desc, blob)
+    roots = good.synthetic_roots()
+    good.search(roots)
+    want = good.results()
+    good.close()
+    monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
+    e = native.HipEngine(**kw)
+    e.set_weights(desc, blob)
+    with pytest.raises(_capi.EngineError, match="team kernel timed out"):
+        e.search(roots)
+        e.results()
+    e.search(roots)          # per-layer launches from here on
+    got = e.results()
+    e.close()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
 def test_config_e_persistent_kernel_equals_lockstep(native, monkeypatch):
