@@ -70,7 +70,10 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
     if (threadIdx.x == 0) {
         int ok = 1;
         unsigned spins = 0;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (T.spin_limit == 0u) {   // (tests: every wait counts as timed out)
+            __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+        } else while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 15u) == 0u) {
                 if (spins > T.spin_limit) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
