@@ -25,6 +25,13 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C alphazero_gym_amd/csrc` (hipcc, gfx950). This package has no CPU fallback."
             )
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's), and the
+        # dynamic linker gives every later library whichever copy was loaded first.  If this engine came first and pulled in the
+        # system runtime, a later torch.cuda initialisation fails ("No HIP GPUs are available"); so torch, when present, goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _fns = _capi.bind(_lib, "azg_")
         ver = _fns["abi_version"]()

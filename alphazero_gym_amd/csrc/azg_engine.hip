@@ -108,20 +108,23 @@ static bool use_lockstep(const azg_engine* e) {
     return e->HP >= 512 && e->n_hidden >= 2 && !e->P.layernorm;
 }
 
-// The persistent team kernel leaves instead of hanging when one of its waits times out (workgroups not co-resident): it raises
-// a word that is read here, after the stream has been synchronised.  From then on the engine uses the per-layer launches.
+// The persistent team kernel leaves instead of hanging when one of its waits times out (its workgroups were not all resident,
+// e.g. another process holds part of the GPU): it raises a word that is read here, after the stream has been synchronised.
+// The search is then run again, with the same search index, as per-layer launches -- which the engine uses from then on.
+extern "C" int azg_search_resident(azg_engine* e);
 static int team_check(azg_engine* e) {
     if (!e->team_pending) return AZG_OK;
     e->team_pending = 0;
     unsigned flag = 0;
     if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
-    if (flag != 0) {
-        e->opt.ls_team = 0;
-        e->searched = 0;
-        return fail(e, AZG_E_DEVICE, "the persistent team kernel timed out (its workgroups were not all resident); the engine now uses "
-                                     "the per-layer launches: search again");
-    }
+    if (flag == 0) return AZG_OK;
+    e->opt.ls_team = 0;
+    e->team_fallbacks += 1;
+    e->search_idx = e->team_search_idx;
+    int rc = azg_search_resident(e);
+    if (rc) return rc;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, AZG_E_DEVICE, "hipStreamSynchronize failed");
     return AZG_OK;
 }
 
@@ -177,7 +180,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
     { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
-    e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0;
+    e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0; e->team_fallbacks = 0; e->team_search_idx = 0;
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr;
     e->carry_max = 0;
@@ -479,6 +482,7 @@ int azg_search_resident(azg_engine* e) {
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
     ON_DEVICE(e);
     e->P.search_idx = e->search_idx;
+    e->team_search_idx = e->search_idx;
     const bool lockstep = use_lockstep(e);
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
@@ -642,6 +646,9 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     return AZG_OK;
 }
 
+// diagnostic: searches that the persistent team kernel gave up on and the per-layer launches redid
+int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1; }
+
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
@@ -729,6 +736,11 @@ int azg_selfplay_step(azg_engine* e) {
     int rc = azg_search_resident(e);
     if (rc) return rc;
     ON_DEVICE(e);
+    if (e->team_pending) {   // (wide networks: the persistent team kernel may have given up -- see team_check)
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        rc = team_check(e);
+        if (rc) return rc;
+    }
     // ReplayBuffer.store (buffers.py:75-82) for this step's block of n_trees rows
     int slot;
     if (e->sp_steps < e->sp_cap) { slot = e->sp_steps; e->sp_steps += 1; }

@@ -21,7 +21,7 @@ struct EngineOptions {
     int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of
                                // different queues do not share the chip well)
     int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256);
-                               // 2: made inside the first hidden layer's staging (+1 %)
+                               // (made inside the first hidden layer's operand staging it cost +1 %: removed)
     int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
     long team_spin_limit;      // AZG_TEAM_SPIN_LIMIT=n: polls a team hand-off may wait before the launch gives up (tests: 0)
 };
@@ -63,6 +63,8 @@ struct azg_engine {
     hipEvent_t ls_fork, ls_join[LS_MAX_PIPES];
     unsigned* d_team_cnt; size_t team_cnt_bytes;   // team kernel: hand-off counters + abort word
     int team_pending;        // a team kernel has been launched since its abort word was last read
+    int team_fallbacks;      // searches it gave up on (redone by the per-layer launches)
+    uint32_t team_search_idx;
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;

@@ -241,13 +241,8 @@ struct TileMem {
     }
 };
 
-// L0IN (first hidden->hidden layer only): the B operand is not read from memory but made here -- the first network layer
-// (K = obs_dim <= 4: one MFMA k-step per tile, then the activation) of this chunk's 4 input tiles for the block's tree groups,
-// computed straight into the B stage in the slots where the other layers store their loaded activations.  It saves the
-// first-layer kernel at the price of every unit slice recomputing those tiles (as a launch of its own it measured slightly
-// slower than the separate first-layer kernel; the team kernel uses it because it saves a hand-off).
 // One output tile of a hidden->hidden layer: TG tree groups (from g0) x UT unit tiles (slice us), by one 256-thread workgroup.
-template <int HP, bool LAST, int TG, int UT, bool L0IN, bool SC1>
+template <int HP, bool LAST, int TG, int UT, bool SC1>
 __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab, bool wt = true) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
@@ -263,33 +258,17 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     const int t0 = us * UT;                          // the UT output tiles
     const int wg = wave % TG, wt0 = (wave / TG) * WT;   // this wave: tree group g0 + wg, tiles t0 + wt0 .. + WT
     const f32x4* W = P.Wl[layer - 1];
-    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1], wt), parts(L.parts, wt), obs(L.obsT);
+    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1], wt), parts(L.parts, wt);
     f32x4 ra[NLA], rb[NLB];
-    // L0IN: B piece jj is tree group jj, and in it this wave's entry is input tile c * KC + wave (KC * 64 == 256 threads):
-    // first-layer weights of that tile (one per chunk, for both groups) and the groups' observations (once)
-    static_assert(!L0IN || (NLB == TG && KC * 64 == 256), "L0IN: one B piece per tree group, one k-block per wave");
-    float w0r = 0.0f, bo[TG];
-    f32x4 b0r = {0.0f, 0.0f, 0.0f, 0.0f};
-    if constexpr (L0IN) {
-#pragma unroll
-        for (int i = 0; i < TG; ++i) bo[i] = obs.load1((size_t)(g0 + i) * 64 + lane);
-    }
     // piece j of a chunk's staging: NLA float4 of the weights, then NLB of the activations, per thread
     auto load_one = [&](int c, int j) {
         const int jj = j < NLA ? j : j - NLA;
         const int e = jj * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);   // tile / tree group, offset in its chunk
         if (j < NLA) ra[jj] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
-        else if constexpr (L0IN) {
-            if (jj == NLB - 1) {   // behind the chunk's last B store: the registers are free for the next chunk's tile
-                w0r = P.W0[(c * KC + wave) * 64 + lane];
-                b0r = P.b0[(c * KC + wave) * 64 + lane];
-            }
-        } else rb[jj] = in.load4(((size_t)(g0 + i) * S4 + c * KC) * 64 + r);
+        else rb[jj] = in.load4(((size_t)(g0 + i) * S4 + c * KC) * 64 + r);
     };
     auto store_one = [&](int st, int j) {
         if (j < NLA) s_ab[st * STAGE + j * 256 + tid] = ra[j];
-        else if constexpr (L0IN)
-            s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = act4<true>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(w0r, bo[j - NLA], b0r, 0, 0, 0));
         else s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = rb[j - NLA];
     };
     auto load_chunk = [&](int c) {
@@ -406,7 +385,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
 }
 
 // A hidden->hidden layer as a launch of its own: one tile per workgroup.
-template <int HP, bool LAST, int TG, int UT, bool L0IN = false>
+template <int HP, bool LAST, int TG, int UT>
 __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {
     constexpr int NU = HP / (16 * UT);
     extern __shared__ f32x4 s_ab[];                        // two stages
@@ -426,5 +405,5 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
         if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
         us = m / TQ; tq = m % TQ;
     }
-    ls_tile<HP, LAST, TG, UT, L0IN, false>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
+    ls_tile<HP, LAST, TG, UT, false>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
 }

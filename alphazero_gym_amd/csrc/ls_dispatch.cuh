@@ -31,17 +31,12 @@ static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
     // (32 trees x 64 units per workgroup: two workgroups per CU at 1024 trees x 1024 units)
     auto tkh = ls_hidden_tiled_kernel<HP, false, 2, 4>;
     auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
-    auto tkh0 = ls_hidden_tiled_kernel<HP, false, 2, 4, true>;   // first hidden layer with the network's first layer made in its staging
-    auto tkl0 = ls_hidden_tiled_kernel<HP, true, 2, 4, true>;
     const int TQ_all = (G + 1) / 2, NU = HP / 64;
     const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
     const bool tiled = e->opt.ls_tiled != 0;
-    const bool l0in = tiled && e->opt.ls_fuse0 == 2;
     if (tiled) {
         hipError_t rc = hipFuncSetAttribute((const void*)tkh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
         if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
-        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkh0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
-        if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)tkl0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
         if (rc != hipSuccess) return rc;
     }
     int pipes = e->opt.ls_pipes;
@@ -62,11 +57,11 @@ static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
         if (g_base + Gp > G) Gp = G - g_base;
         hipLaunchKernelGGL(tk, dim3(Gp), dim3(256), tab_bytes, st, e->P, e->ls, -2, g_base);
         for (int sim = -1; sim < e->cfg.n_sims; ++sim) {
-            if (!fuse0 && !l0in) hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(Gp * NS), dim3(256), 0, st, e->P, e->ls, g_base);
+            if (!fuse0) hipLaunchKernelGGL((ls_layer0_kernel<HP>), dim3(Gp * NS), dim3(256), 0, st, e->P, e->ls, g_base);
             for (int l = 1; l < e->n_hidden; ++l) {
                 const bool last = l == e->n_hidden - 1;
                 if (tiled) {
-                    auto k = last ? (l == 1 && l0in ? tkl0 : tkl) : (l == 1 && l0in ? tkh0 : tkh);
+                    auto k = last ? tkl : tkh;
                     hipLaunchKernelGGL(k, dim3(TQ * NU), dim3(256), tiled_bytes, st, e->P, e->ls, l, (l - 1) & 1, TQ, g_base);
                 } else if (last) {
                     hipLaunchKernelGGL(hl, dim3(Gp * NS), dim3(256), act_bytes, st, e->P, e->ls, l, (l - 1) & 1, g_base);

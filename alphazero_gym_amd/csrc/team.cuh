@@ -14,9 +14,10 @@
 // every handed-off byte is stored AND loaded with sc1 buffer instructions (TileMem<true>: write-through past the L2, loads
 // around the L1); an arriving workgroup drains its stores (s_waitcnt vmcnt(0) in every wave), meets at its barrier, then one
 // lane adds to the counter; a waiting workgroup polls with an sc1 load from one lane and releases the others through its
-// barrier.  Placement (blockIdx % 8 = XCD under round-robin dispatch) is used for speed: a team sits on one XCD, and once the
-// team has SEEN at run time that it does (its workgroups' XCC_IDs), its hand-off stores stay plain -- they write through the L1
-// into that XCD's L2, where the team's sc1 loads find them -- instead of going through to memory.
+// barrier.  Placement (blockIdx % 8 = XCD under round-robin dispatch) is used for speed only: by default a team's slices are
+// spread over the XCDs so that each XCD's L2 holds its slices' weights.  (In the other mapping, a team on one XCD, the team
+// checks at run time that it really sits on one -- its workgroups' XCC_IDs -- and then keeps its hand-off stores plain: they
+// write through the L1 into that XCD's L2, where the team's sc1 loads find them.)
 // Deadlock: every workgroup of the grid has to be resident; the host checks the occupancy before choosing this path, and every
 // wait is bounded -- on a time-out the launch raises an abort flag, all workgroups leave, and the host falls back.
 // The arithmetic is the lock-step path's (ls_tile, tree_phase_a/b): bit-identical results.
@@ -35,6 +36,9 @@
 #define TEAM_MAX_CNT 8          // counter 0: first layer of the step written; l: hidden layer l written
 #define TEAM_CNT_XA (TEAM_MAX_CNT - 1)   // max XCC_ID of the team's workgroups
 #define TEAM_CNT_XB (TEAM_MAX_CNT - 2)   // max (7 - XCC_ID)
+#ifndef TEAM_SPREAD
+#define TEAM_SPREAD 1           // 1: a team's unit slices spread over the XCDs (weights L2-resident); 0: a team on one XCD
+#endif
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
@@ -112,6 +116,14 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     // team and slice of this workgroup: the NU workgroups of a team have equal blockIdx % 8 (one XCD under round-robin placement)
     int tq, us;
+#if TEAM_SPREAD
+    // A team's slices are SPREAD over the XCDs (blockIdx % 8 = XCD under round-robin dispatch: NU / 8 slices on each), so that
+    // every XCD's 4 MB L2 keeps just its own slices' weights resident (1.5 MB at 4x1024) instead of streaming all 12.6 MB of them
+    // from the Infinity Cache every step; the hand-offs then cross XCDs (sc1 stores and loads).  Measured 13.3 ms per search
+    // against 14.5 ms with each team on one XCD (plain hand-off stores into its L2): the weights matter more.
+    if (NU % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8, sp = NU / 8; tq = j / sp; us = x * sp + j % sp; }
+    else
+#endif
     if (TQ % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8; tq = x * (TQ / 8) + j / NU; us = j % NU; }
     else { tq = blockIdx.x / NU; us = blockIdx.x % NU; }
     const int g0 = 2 * tq;                                   // the team's tree groups g0, g0 + 1
@@ -209,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
-            if (l == n_layers) ls_tile<HP, true, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab, wt);
-            else ls_tile<HP, false, 2, 4, false, true>(P, L, l, in_buf, us, g0, s_ab, wt);
+            if (l == n_layers) ls_tile<HP, true, 2, 4, true>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile<HP, false, 2, 4, true>(P, L, l, in_buf, us, g0, s_ab, wt);
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
             if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;

@@ -326,8 +326,9 @@ def main():
                              ["search_kernel<0, 128, 1, 1, false, 4, 1>"], 0.26 * mlp_flops(4, [128, 128], 3),
                              "tree-walk bound (9.2 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction", dev),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
-                             ["ls_tree_kernel<2, false, 16>", "ls_hidden_tiled_kernel<1024, false, 2, 4>", "ls_hidden_tiled_kernel<1024, true, 2, 4>"],
-                             mlp_flops(3, [1024] * 4, 3), "lock-step path: per simulation step one tree kernel + one kernel per hidden layer", dev),
+                             ["ls_team_kernel<2, 1024, false, 1>"],
+                             mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
+                             "layer for the team's 32 trees each), hand-offs through global memory", dev),
             ]
         out = {
             "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",

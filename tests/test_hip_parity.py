@@ -285,29 +285,39 @@ def test_config_e_full_size_lockstep(native):
 
 
 def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
-    """The persistent team kernel's waits are bounded: with a spin limit of zero the launch aborts, the engine reports it and
-    falls back to the per-layer launches, and the next search is complete and identical to a clean engine's."""
+    """The persistent team kernel's waits are bounded (its workgroups must all be resident: another process on the GPU can
+    prevent that).  With a spin limit of zero every wait counts as timed out: the launch leaves, the engine notices, redoes the
+    search with the per-layer launches under the same search index, and stays on them -- the caller sees complete, identical
+    results.  Also inside a self-play step, whose final-action kernel must not consume an abandoned search."""
+    import ctypes as C
     kw = dict(env_id=2, mode=1, n_trees=64, n_sims=20, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=3)
     desc = _capi.make_desc(3, [512, 512], 2, "elu")
     blob = O.make_weights(5, 3, [512, 512], 2)
-    good = native.HipEngine(**kw)
-    good.set_weights(desc, blob)
-    roots = good.synthetic_roots()
-    good.search(roots)
-    want = good.results()
-    good.close()
-    monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
-    e = native.HipEngine(**kw)
-    e.set_weights(desc, blob)
-    with pytest.raises(_capi.EngineError, match="team kernel timed out"):
-        e.search(roots)
-        e.results()
-    e.set_search_index(0)    # (the aborted search consumed an index: same noise as the clean engine's first search)
-    e.search(roots)          # per-layer launches from here on
-    got = e.results()
-    e.close()
-    for k in want:
-        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+    def run(selfplay):
+        e = native.HipEngine(**kw)
+        e.set_weights(desc, blob)
+        if selfplay:
+            e.selfplay_begin(50, capacity_steps=3)
+            for _ in range(3):
+                e.selfplay_step()
+            out = {"rows": e.selfplay_rows(clear=False)}
+        else:
+            e.search(e.synthetic_roots())
+            e.search(e.synthetic_roots())
+            out = dict(e.results(), **e.dump_tree())
+        n = native.lib().azg_debug_team_fallbacks(C.c_void_p(e._h.value))
+        e.close()
+        return out, n
+
+    for selfplay in (False, True):
+        monkeypatch.delenv("AZG_TEAM_SPIN_LIMIT", raising=False)
+        want, n0 = run(selfplay)
+        monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
+        got, n1 = run(selfplay)
+        assert n0 == 0 and n1 == 1, (n0, n1)      # the first search fell back, the later ones went straight to the launches
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
 def test_config_e_persistent_kernel_equals_lockstep(native, monkeypatch):
