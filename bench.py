@@ -322,6 +322,9 @@ def main():
                                     "note": "the same self-play loop without the all-gather and the weight broadcast"}
         elif not args.no_extra:
             extra["configs"] = [
+                extra_config("C at 8192 trees per GPU (the batch shape of real self-play runs: two 16-tree groups per CU)", PENDULUM, 8192, 200, 3, HIDDEN, 2, "elu",
+                             ["search_kernel<2, 256, 1, 1, false, 8, 2>"], FLOP_PER_SIM,
+                             "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
                              ["search_kernel<0, 128, 1, 1, false, 4, 1>"], 0.26 * mlp_flops(4, [128, 128], 3),
                              "tree-walk bound (9.2 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction", dev),
