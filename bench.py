@@ -135,14 +135,14 @@ def cpu_baseline():
     rall, dtall, repsall = oracle_rate(cores, nall, 8.0)
     procs = min(cores, 64)
     t0 = time.perf_counter()
-    rpy = pytree.throughput("pendulum", n_rollouts=N_SIMS, hidden=HIDDEN, processes=procs, trees_per_process=2)
+    rpy = pytree.throughput("pendulum", n_rollouts=N_SIMS, hidden=HIDDEN, processes=procs, trees_per_process=8)
     dtpy = time.perf_counter() - t0
     return {"value": rall, "unit": "sims/s", "cores": cores, "kind": "port",
             "sample": f"{repsall} searches of {nall} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle, OpenMP over trees on "
                       f"{cores} threads (physical cores {physical_cores()}, usable CPUs {usable_cpus()}, logical CPUs {os.cpu_count()}), {dtall:.1f} s",
             "single_thread": {"value": r1, "unit": "sims/s", "cores": 1, "sample": f"{reps1} searches of {n1} trees x {N_SIMS} sims, {dt1:.1f} s"},
             "python_object_tree": {"value": rpy, "unit": "sims/s", "cores": procs, "kind": "port",
-                                   "sample": f"{procs} processes x 2 trees x {N_SIMS} sims, 1 torch thread each, oracle/pytree.py "
+                                   "sample": f"{procs} processes x 8 trees x {N_SIMS} sims, 1 torch thread each, oracle/pytree.py "
                                              f"(the reference's cost structure: batch-1 torch forwards, env replay, numpy UCT), {dtpy:.1f} s incl. start-up"}}
 
 
