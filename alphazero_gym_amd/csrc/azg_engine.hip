@@ -113,13 +113,31 @@ static bool use_lockstep(const azg_engine* e) {
 // The search is then run again, with the same search index, as per-layer launches -- which the engine uses from then on.
 extern "C" int azg_search_resident(azg_engine* e);
 static int team_check(azg_engine* e) {
-    if (!e->team_pending) return AZG_OK;
-    e->team_pending = 0;
+    if (!e->team_pending && !e->pair_pending) return AZG_OK;
     unsigned flag = 0;
-    if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
+    if (e->team_pending) {
+        e->team_pending = 0;
+        if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
+        if (flag) e->opt.ls_team = 0;
+    } else {
+        // (the walker + server pair of pair.cuh gives up the same way; the search is rerun by the one-kernel form)
+        e->pair_pending = 0;
+        if (hipMemcpy(&flag, e->d_pair_cnt + (e->pair_cnt_words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(e, AZG_E_DEVICE, "reading the kernel pair's status failed");
+        if (flag) e->opt.pair = 0;
+        if (flag && getenv("AZG_DEBUG")) {
+            unsigned tail[64];
+            if (hipMemcpy(tail, e->d_pair_cnt + (e->pair_cnt_words - 64), sizeof(tail), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "azgym pair gave up; walkers started per XCD:");
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", tail[i]);
+                fprintf(stderr, "; servers:");
+                for (int i = 8; i < 16; ++i) fprintf(stderr, " %u", tail[i]);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     if (flag == 0) return AZG_OK;
-    e->opt.ls_team = 0;
     e->team_fallbacks += 1;
     e->search_idx = e->team_search_idx;
     int rc = azg_search_resident(e);
@@ -149,6 +167,13 @@ void azg_engine_destroy(azg_engine* e) {
         if (e->ls_join[p]) (void)hipEventDestroy(e->ls_join[p]);
     }
     if (e->ls_fork) (void)hipEventDestroy(e->ls_fork);
+    if (e->pair_stream) (void)hipStreamSynchronize(e->pair_stream);
+    if (e->d_pair_obs) (void)hipFree(e->d_pair_obs);
+    if (e->d_pair_parts) (void)hipFree(e->d_pair_parts);
+    if (e->d_pair_cnt) (void)hipFree(e->d_pair_cnt);
+    if (e->pair_fork) (void)hipEventDestroy(e->pair_fork);
+    if (e->pair_join) (void)hipEventDestroy(e->pair_join);
+    if (e->pair_stream) (void)hipStreamDestroy(e->pair_stream);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -180,7 +205,10 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
     { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
+    e->opt.pair = env_digit("AZG_PAIR", 0);
     e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0; e->team_fallbacks = 0; e->team_search_idx = 0;
+    e->d_pair_obs = nullptr; e->d_pair_parts = nullptr; e->d_pair_cnt = nullptr; e->pair_cnt_words = 0; e->pair_alloc_pairs = 0; e->pair_alloc_per = 0;
+    e->pair_stream = nullptr; e->pair_fork = nullptr; e->pair_join = nullptr; e->pair_pending = 0; e->kernel_form = -1;
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr;
     e->carry_max = 0;
@@ -489,8 +517,14 @@ int azg_search_resident(azg_engine* e) {
     hipError_t rc;
     const bool cartpole = e->cfg.env_id == AZG_ENV_CARTPOLE;
     if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : azg_ls_dispatch_pendulum(e);
-    else if (cartpole) rc = azg_dispatch_cartpole(e);
-    else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
+    else {
+        rc = hipErrorNotReady;
+        if (e->opt.pair) rc = cartpole ? azg_pair_dispatch_cartpole(e) : azg_pair_dispatch_pendulum(e);
+        if (rc == hipErrorNotReady) {
+            if (cartpole) rc = azg_dispatch_cartpole(e);
+            else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
+        }
+    }
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;
@@ -527,7 +561,7 @@ static int gather_results(azg_engine* e) {
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     if (e->results_valid) return AZG_OK;
     ON_DEVICE(e);
-    if (e->team_pending) {
+    if (e->team_pending || e->pair_pending) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         int trc = team_check(e);
         if (trc) return trc;
@@ -648,6 +682,8 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
 
 // diagnostic: searches that the persistent team kernel gave up on and the per-layer launches redid
 int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1; }
+// diagnostic: the form the last search ran in (engine_host.h: kernel_form)
+int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
@@ -736,7 +772,7 @@ int azg_selfplay_step(azg_engine* e) {
     int rc = azg_search_resident(e);
     if (rc) return rc;
     ON_DEVICE(e);
-    if (e->team_pending) {   // (wide networks: the persistent team kernel may have given up -- see team_check)
+    if (e->team_pending || e->pair_pending) {   // (wide networks: the persistent team kernel may have given up -- see team_check)
         HIPCHK(e, hipStreamSynchronize(e->stream));
         rc = team_check(e);
         if (rc) return rc;

@@ -35,6 +35,7 @@ static hipError_t launch_g(azg_engine* e) {
     e->tree_lds = TLDS;
     e->dyn_lds = L.total;
     e->waves = NW; e->groups = NG;
+    e->kernel_form = 0;
     hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
     return hipGetLastError();
 }

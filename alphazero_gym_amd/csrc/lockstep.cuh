@@ -232,6 +232,12 @@ struct TileMem {
         if constexpr (SC1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4), 0, 16));
         else return ((const float*)p)[i];
     }
+    __device__ __forceinline__ void store1(size_t i, float v) const {
+        if constexpr (SC1) {
+            if (wt) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)(i * 4), 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)(i * 4), 0, 0);
+        } else ((float*)p)[i] = v;
+    }
     __device__ __forceinline__ void store4(size_t i, f32x4 v) const {
         if constexpr (SC1) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

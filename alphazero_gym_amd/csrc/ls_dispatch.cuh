@@ -87,6 +87,7 @@ static hipError_t ls_run(azg_engine* e) {
         hipError_t rc = ENV == AZG_ENV_CARTPOLE ? azg_team_dispatch_cartpole(e) : azg_team_dispatch_pendulum(e);
         if (rc != hipErrorNotReady) return rc;
     }
+    e->kernel_form = 1;
     return ls_enqueue<ENV, HP, GMM>(e, e->stream);
 }
 

@@ -40,6 +40,7 @@ static hipError_t team_launch(azg_engine* e) {
     T.spin_limit = (unsigned)e->opt.team_spin_limit;
     hipLaunchKernelGGL(kern, dim3(TQ * NU), dim3(256), lds, e->stream, e->P, e->ls, T, TQ);
     e->team_pending = 1;
+    e->kernel_form = 2;
     e->tree_lds = TLDS;
     e->dyn_lds = lds;
     return hipGetLastError();

@@ -49,12 +49,21 @@ def test_mfma_f32_is_a_k_ordered_fma_chain(native):
     assert np.float32(dev) == chain, (dev, chain, acc)
 
 
-def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0):
+def _kernel_form(e):
+    """What the HIP engine's last search ran as (engine_host.h: 0 search kernel, 1 per-layer launches, 2 team kernel, 3 kernel pair)."""
+    import ctypes as C
+    from alphazero_gym_amd import _native
+    return _native.lib().azg_debug_kernel_form(C.c_void_p(e._h.value))
+
+
+def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0, forms=None):
     e = engine_cls(**kw)
     e.set_weights(desc, blob)
     e.set_search_index(sidx)
     e.search(roots, carry)
     out = (e.results(), e.dump_tree(), e.root_children(), e.root_eval())
+    if forms is not None:
+        forms.append(_kernel_form(e))
     e.close()
     return out
 
@@ -122,13 +131,13 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2", "pair"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
     instead of LDS, for wide networks (default: the persistent team kernel) the one-launch search kernel and the per-layer
     launches, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
-    itself only for batches of more 16-tree groups than CUs)."""
+    itself only for batches of more 16-tree groups than CUs), and the walker + server kernel pair (same condition)."""
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
     ncomp = extra.pop("_ncomp", 0)
@@ -141,6 +150,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         if hidden != [256, 256] or ln or ncomp:
             pytest.skip("the 8-wave workgroups exist for 2x256 Normal / 2-action networks")
         monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
+    if variant == "pair":
+        if hidden not in ([256, 256], [128, 128]) or act not in ("relu", "elu") or ln or ncomp:
+            pytest.skip("the kernel pair exists for 2x256 / 2x128 Normal / 2-action networks")
+        monkeypatch.setenv("AZG_PAIR", "2")
     if variant in ("persistent", "launches"):
         if max(hidden) <= 256:
             pytest.skip("lock-step kernels only exist for hidden widths >= 512")
@@ -162,9 +175,14 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         roots[3] = [2.35, 1.5, 0.0, 0.0]      # terminates quickly
         roots[5] = [0.0, 0.0, 0.2, 1.0]
     carry = (np.arange(B) % 7).astype(np.int32) if mode == 0 else None
-    a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3)
+    forms = []
+    a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3, forms=forms)
     b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=3)
     _assert_same(a, b)
+    if variant == "pair":
+        # (the pair keeps its trees in LDS with 8-bit ids: at most 255 records and 16 children per node)
+        eligible = a[1]["edge_n"].shape[1] <= 255 and a[0]["counts"].shape[1] <= 16
+        assert forms == ([3] if eligible else [0]), "the search did not run as the walker + server pair"
 
 
 @pytest.mark.parametrize("big", [False, True])
@@ -282,6 +300,36 @@ def test_config_e_full_size_lockstep(native):
         for k in do:
             np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=k)
     assert ms < 40.0, f"config E search took {ms:.1f} ms (measured 16.6 ms in round 1)"
+
+
+def test_kernel_pair_gives_up_instead_of_hanging(native, monkeypatch):
+    """The walker + server kernel pair (pair.cuh, AZG_PAIR) needs both kernels resident at once; its waits are bounded the same
+    way as the team kernel's.  Spin limit zero: the pair leaves at its first wait, the engine reruns the search as the
+    one-kernel form under the same search index and stays on it."""
+    import ctypes as C
+    kw = dict(env_id=2, mode=1, n_trees=70, n_sims=30, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=3)
+    desc = _capi.make_desc(3, [256, 256], 2, "elu")
+    blob = O.make_weights(5, 3, [256, 256], 2)
+
+    def run():
+        e = native.HipEngine(**kw)
+        e.set_weights(desc, blob)
+        e.search(e.synthetic_roots())
+        e.search(e.synthetic_roots())
+        out = dict(e.results(), **e.dump_tree())
+        h = C.c_void_p(e._h.value)
+        n, form = native.lib().azg_debug_team_fallbacks(h), native.lib().azg_debug_kernel_form(h)
+        e.close()
+        return out, n, form
+
+    monkeypatch.setenv("AZG_PAIR", "2")
+    ref, n, form = run()
+    assert (n, form) == (0, 3)
+    monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
+    out, n, form = run()
+    assert (n, form) == (1, 0)
+    for k in ref:
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
 
 
 def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
