@@ -684,6 +684,22 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
 int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1; }
 // diagnostic: the form the last search ran in (engine_host.h: kernel_form)
 int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
+// diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
+// head, waves, tree groups -- see search_kernel.cuh / team.cuh / pair.cuh); returns the length written
+int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
+    if (!e || !buf || n == 0) return AZG_E_INVALID;
+    const int env = e->cfg.env_id == AZG_ENV_CARTPOLE ? 0 : 2;   // (both Pendulum versions run the ENV = 2 instantiation)
+    const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
+    int w = 0;
+    switch (e->kernel_form) {
+        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups); break;
+        case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
+        case 2: w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d>", env, e->HP, gmm, e->tree_lds); break;
+        case 3: w = snprintf(buf, n, "pair_walker_kernel<%d, %d, %d, %s> + pair_server_kernel<%d, %d, %s>", env, e->HP, e->tree_lds, gmm, e->HP, e->nreg, gmm); break;
+        default: w = snprintf(buf, n, "(no search yet)");
+    }
+    return w;
+}
 
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {

@@ -22,13 +22,14 @@
 // wait is bounded -- on a time-out the launch raises an abort flag, all workgroups leave, and the host falls back.
 // The arithmetic is the lock-step path's (ls_tile, tree_phase_a/b): bit-identical results.
 //
-// Measured at config E (1024 trees, 4x1024, MI355X): 14.4-14.8 ms per search against 15.6-15.9 ms for the per-layer launches;
-// per step (tools/team_profile.py, 161k cycles): the three tiles 108k (two workgroups per CU side by side: 93 % of the matrix
-// pipe's time while they run), hand-off waits 23k, tree phases + first layer 22k.  The two workgroups of a CU (blocks b and
-// b + 256: tools/team_census.py) belong to different teams; shifting one team by half a step or gating it on its partner's
-// progress did not pay (two tiles side by side take 35k cycles, one alone 24k: running them together is the efficient
-// state), nor did making the first layer inside the first hidden layer's staging (+18k cycles per step) or as a team phase
-// of MFMA tiles behind an observation hand-off (same time as the vector-ALU form here, one hand-off more).
+// Measured at config E (1024 trees, 4x1024, MI355X): 13.3 ms per search against 14.9 ms for the per-layer launches (16.6 ms in
+// round 1).  Per step (tools/team_profile.py, 153k cycles = 64 us): the three tiles 104k (two workgroups per CU side by side:
+// 94 % of the matrix pipe's rate while they run), hand-off waits 21k (4 per step, across XCDs), tree phases + first layer
+// 21k.  The two workgroups of a CU (blocks b and b + 256: tools/team_census.py) belong to different teams; shifting one team
+// by half a step or gating it on its partner's progress did not pay (two tiles side by side take 35k cycles, one alone 24k:
+// running them together is the efficient state), nor did making the first layer inside the first hidden layer's staging
+// (+18k cycles per step) or as a team phase of MFMA tiles behind an observation hand-off (same time as the vector-ALU form
+// here, one hand-off more).
 #pragma once
 #include "lockstep.cuh"
 

@@ -158,6 +158,15 @@ def time_search(eng, steps, warmup):
     return float(np.median(ms)), float(np.mean(ms))
 
 
+def kernel_name(eng):
+    """The kernel(s) the engine's last search ran as, in rocprofv3's spelling (the engine's own account, not a constant here)."""
+    import ctypes as C
+    from alphazero_gym_amd import _native
+    buf = C.create_string_buffer(256)
+    n = _native.lib().azg_debug_kernel_name(C.c_void_p(eng._h.value), buf, C.c_size_t(256))
+    return buf.value.decode() if n > 0 else "?"
+
+
 def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, kernels, flops_per_sim, note, device_id):
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
@@ -167,6 +176,8 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, kernels, 
     med, mean = time_search(eng, 7, 2)
     res = eng.results()
     assert (res["counts"].sum(1) == n_sims).all()
+    ran = kernel_name(eng)
+    assert ran == kernels[0], f"{name}: expected {kernels[0]}, the engine ran {ran}"
     eng.close()
     ach = trees * n_sims * flops_per_sim / (med * 1e-3) / 1e12
     return {"config": name, "ms_per_search": med, "ms_mean": mean, "sims_per_s": trees * n_sims / (med * 1e-3), "trees": trees, "n_sims": n_sims,
@@ -313,6 +324,7 @@ def main():
             t = torch.tensor([plain], device="cpu" if args.backend != "nccl" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             plain = float(t.item())
+    kname = kernel_name(eng)
     eng.close()
     if rank == 0:
         sims = world * B * N_SIMS * args.steps
@@ -341,8 +353,8 @@ def main():
             "config": {"workload": workload, "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": profiled_traffic() if B == N_TREES else None,
-                         "kernel": "search_kernel<2, 256, 1, 1, false, 4, 1> (ENV=Pendulum, HP=256, NREG=1, trees in LDS with 8-bit ids, no GMM, 4 waves, 1 tree group)"
-                                   if B <= 4096 else "search_kernel<2, 256, 1, 1, false, 8, 2> (8 waves, 2 tree groups per workgroup)",
+                         "kernel": kname + " (template arguments: ENV 2 = Pendulum, HP = padded hidden width, NREG = hidden->hidden layers held in "
+                                   "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup, 16-tree groups per workgroup)",
                          "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
