@@ -22,9 +22,9 @@
 // Measured (MI355X, 8192 trees x 200 simulations, 2x256 ELU; tools/time_pair.py, tools/pair_profile.py): bit-identical
 // results, 3.15 ms per search against 2.67 ms for search_kernel<..., 8, 2>.  Per half-step (one group's evaluation + walk) the
 // server is busy 14.4k cycles (network 13.7k; 12.1k when it has the SIMDs to itself) and the walker 15.4k (finish leaf +
-// backup 3.5k, select / step / expand 10.6k -- 1.9k and 5.4k without a network running beside it): the tree walk is bound by
-// instruction issue on its SIMD, not by latency, so a wave of MFMAs next to it (each holds the vector issue port for 8 of its
-// 32 cycles) slows it as much as a second walker would, and what the overlap wins the contention takes back.  With the two
+// backup 3.5k, select / step / expand 10.6k -- 1.9k and 5.4k without a network running beside it): next to a wave that issues
+// MFMAs back to back every vector instruction of another wave costs 8 cycles more (tools/probes/valu_rate.hip; s_setprio does
+// not change it), about 650 of them per walk, and what the overlap wins that tax takes back.  With the two
 // workgroups of a pair on different XCDs (sc1 hand-offs, about 7k cycles each) it was 3.7 ms.
 #pragma once
 #include "records.h"
