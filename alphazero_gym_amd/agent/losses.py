@@ -8,7 +8,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-class AlphaZeroLoss(nn.Module):
+class Loss(nn.Module):
+    """What every loss of this module is: a module whose forward returns a dict with at least "loss", "policy_loss" and
+    "value_loss" (the reference's abstract base, losses.py:12-27)."""
+
+    def forward(self, *args, **kwargs) -> Dict[str, torch.Tensor]:
+        raise NotImplementedError
+
+
+class AlphaZeroLoss(Loss):
     """policy_coeff * CE(logits, argmax of the MCTS policy) + value_coeff * MSE(V_hat, V)."""
 
     def __init__(self, policy_coeff: float, value_coeff: float, reduction: str) -> None:
@@ -22,7 +30,7 @@ class AlphaZeroLoss(nn.Module):
         return {"loss": policy_loss + value_loss, "policy_loss": policy_loss, "value_loss": value_loss}
 
 
-class A0CLoss(nn.Module):
+class A0CLoss(Loss):
     """A0C loss: REINFORCE-style policy term sum_i (log pi_i - tau log n_i).detach() * log pi_i, entropy bonus, value MSE."""
 
     def __init__(self, tau: float, policy_coeff: float, alpha: Union[float, torch.Tensor], value_coeff: float, reduction: str) -> None:

@@ -29,6 +29,13 @@ def check_space(space):
     raise NotImplementedError("This type of space is not supported")
 
 
+def get_base_env(env):
+    """The innermost environment under any stack of gym-style wrappers (helpers.py:95-99)."""
+    while hasattr(env, "env"):
+        env = env.env
+    return env
+
+
 def store_actions(name: str, to_store: np.ndarray) -> None:
     """Dump the best action sequence to runs/<name>.npy (helpers.py:81-89)."""
     path = Path("runs/")

@@ -31,7 +31,9 @@ def _trunk(in_dim: int, hidden: List[int], nonlinearity: str, layernorm: bool) -
     return nn.Sequential(*layers)
 
 
-class _PolicyBase(nn.Module):
+class Policy(nn.Module):
+    """Common part of the policy networks (the reference's base class of the same name, policies.py:22-120): trunk + value head."""
+
     def _setup(self, representation_dim, action_dim, hidden_dimensions, nonlinearity, layernorm):
         assert hidden_dimensions, "Hidden dimensions can't be empty."
         self.state_dim = representation_dim
@@ -52,7 +54,7 @@ class _PolicyBase(nn.Module):
         return sum(self.hidden_dimensions)
 
 
-class DiscretePolicy(_PolicyBase):
+class DiscretePolicy(Policy):
     distribution_type = "Categorical"
 
     def __init__(self, representation_dim: int, action_dim: int, num_actions: int, hidden_dimensions: List[int],
@@ -88,8 +90,9 @@ class DiscretePolicy(_PolicyBase):
         return F.softmax(logits, dim=-1).detach().cpu().numpy()
 
 
-class DiagonalNormalPolicy(_PolicyBase):
+class DiagonalNormalPolicy(Policy):
     distribution_type = "Normal"
+    policy_type = "DiagonalNormal"
 
     def __init__(self, representation_dim: int, action_dim: int, action_bound: Optional[float], hidden_dimensions: List[int],
                  nonlinearity: str, layernorm: bool = False, log_param_min: float = -5, log_param_max: float = 2):
@@ -134,7 +137,7 @@ class DiagonalNormalPolicy(_PolicyBase):
         return self._dist(mu, sigma).sample().detach().cpu().numpy()
 
 
-class DiagonalGMMPolicy(_PolicyBase):
+class DiagonalGMMPolicy(Policy):
     """Mixture of `num_components` squashed Normals per state (policies.py:502-669).  dist_head layout:
     [mu_0..mu_C-1 | log_std_0..log_std_C-1 | log_coeff_0..log_coeff_C-1] for action_dim == 1."""
 
@@ -197,6 +200,9 @@ class DiagonalGMMPolicy(_PolicyBase):
         comp = torch.distributions.Categorical(logits=log_coeff).sample().unsqueeze(-1)
         a = self._component(mu, sigma).sample()
         return torch.gather(a, -1, comp).detach().cpu().numpy()
+
+
+_PolicyBase = Policy   # (earlier name)
 
 
 def make_policy(representation_dim: int, action_dim: int, distribution: str, hidden_dimensions: List[int], nonlinearity: str,
