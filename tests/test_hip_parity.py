@@ -272,6 +272,38 @@ def _oracle_block(kw, desc, blob, roots, lo, hi):
     return out
 
 
+def test_config_b_full_size(native):
+    """BASELINE config B (CartPole-v1 discrete, 4096 trees, n_sims 100, 2x128 relu) at size: count invariants on every tree (terminal
+    leaves included: a trace that ends in a terminal node creates no record) and two blocks of trees bit-exact against the oracle."""
+    NS, B = 100, 4096
+    kw = dict(env_id=0, mode=0, n_trees=B, n_sims=NS, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+    desc = _capi.make_desc(4, [128, 128], 2, "relu")
+    blob = O.make_weights(34, 4, [128, 128], 2)
+    e = native.HipEngine(**kw)
+    e.set_weights(desc, blob)
+    roots = e.synthetic_roots()
+    e.search(roots)
+    r, d = e.results(), e.dump_tree()
+    assert _kernel_form(e) == 0
+    e.close()
+    assert (r["counts"].sum(1) == NS).all() and (r["n_children"] == 2).all()
+    assert (d["node_n"][:, 0] == NS).all()
+    assert (d["n_records"] <= 1 + 2 * (NS + 1)).all() and (d["n_records"] % 2 == 1).all()   # the root + two edges per expanded node
+    for t in range(0, B, 97):                                     # node.n == sum of child edge counts unless the node is terminal
+        n = int(d["n_records"][t])
+        par, en, nn, fl = d["parent"][t][:n], d["edge_n"][t][:n], d["node_n"][t][:n], d["node_flags"][t][:n]
+        acc = np.zeros_like(nn)
+        np.add.at(acc, par[1:], en[1:])
+        inner = (fl & 2) == 0                                     # (FLAG_TERMINAL = 2: visits of a terminal node stop there)
+        np.testing.assert_array_equal(acc[inner], nn[inner])
+    for lo in (0, B - 48):
+        ro, do = _oracle_block(kw, desc, blob, roots, lo, lo + 48)
+        for k in ("counts", "Q", "v_target"):
+            np.testing.assert_array_equal(ro[k], r[k][lo:lo + 48], err_msg=k)
+        for k in ("edge_n", "edge_W", "node_n", "parent"):
+            np.testing.assert_array_equal(do[k], d[k][lo:lo + 48], err_msg=k)
+
+
 def test_config_e_full_size_lockstep(native):
     """BASELINE config E per GPU (Pendulum-v1, 1024 trees, n_sims 200, 4x1024 ELU: mcts.py:656-702 at E's tree sizes) on the
     lock-step path: 201 simulation steps of tree / layer kernels over global-memory trees.  Size-independent invariants on
