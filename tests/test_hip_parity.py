@@ -306,7 +306,7 @@ def test_config_b_full_size(native):
 
 def test_config_e_full_size_lockstep(native):
     """BASELINE config E per GPU (Pendulum-v1, 1024 trees, n_sims 200, 4x1024 ELU: mcts.py:656-702 at E's tree sizes) on the
-    lock-step path: 201 simulation steps of tree / layer kernels over global-memory trees.  Size-independent invariants on
+    lock-step path (by default the persistent team kernel: 201 simulation steps in one launch).  Size-independent invariants on
     every tree + 24 trees (both ends and the middle of the batch) bit-exact against the oracle: counts, Q, W, parents."""
     NS, B = 200, 1024
     kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
