@@ -29,6 +29,7 @@ struct EngineOptions {
                                // 8192 trees x 2x256, 3.15 ms per search against 2.67 ms for the 8-wave one-kernel form
 };
 #define LS_MAX_PIPES 8
+#define AZG_MAX_DEVICES 64    // per-device caches of kernel attributes (host side)
 
 struct azg_engine {
     azg_config cfg;

@@ -37,9 +37,12 @@ static hipError_t pair_launch(azg_engine* e) {
     auto server = pair_server_kernel<HP, NREG, GMM>;
     const size_t w_lds = pair_tree_off(e->tab_n, e->cfg.n_sims) + 32 * pair_tree_bytes(e->R, CONT, TLDS);
     const size_t s_lds = (size_t)act_buffers(NREG) * HP * 64;
-    static std::atomic<int> fit_cache{-1};
-    static std::atomic<size_t> lds_cache{0};
-    int fit = fit_cache.load(std::memory_order_relaxed);
+    // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel; stored: 0 = not looked at yet, 1 = does not fit, 2 = fits)
+    static std::atomic<int> fit_caches[AZG_MAX_DEVICES];
+    static std::atomic<size_t> lds_caches[AZG_MAX_DEVICES];
+    std::atomic<int>& fit_cache = fit_caches[e->cfg.device_id % AZG_MAX_DEVICES];
+    std::atomic<size_t>& lds_cache = lds_caches[e->cfg.device_id % AZG_MAX_DEVICES];
+    int fit = fit_cache.load(std::memory_order_relaxed) - 1;
     if (fit < 0 || w_lds != lds_cache.load(std::memory_order_relaxed)) {
         hipFuncAttributes fw, fs;
         hipError_t rc = hipFuncGetAttributes(&fw, (const void*)walker);
@@ -57,7 +60,7 @@ static hipError_t pair_launch(azg_engine* e) {
             rc = hipFuncSetAttribute((const void*)walker, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w_lds);
             if (rc != hipSuccess) return rc;
         }
-        fit_cache.store(fit, std::memory_order_relaxed);
+        fit_cache.store(fit + 1, std::memory_order_relaxed);
         lds_cache.store(w_lds, std::memory_order_relaxed);
     }
     if (!fit) return hipErrorNotReady;

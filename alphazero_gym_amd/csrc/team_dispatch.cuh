@@ -16,10 +16,13 @@ static hipError_t team_launch(azg_engine* e) {
     const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
     if (lds + 1024 > 160 * 1024) return hipErrorNotReady;
     auto kern = ls_team_kernel<ENV, HP, GMM, TLDS>;
-    static std::atomic<int> per_cu_cache{-1};
-    static std::atomic<size_t> lds_cache{0};
+    // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel)
+    static std::atomic<int> per_cu_caches[AZG_MAX_DEVICES];
+    static std::atomic<size_t> lds_caches[AZG_MAX_DEVICES];
+    std::atomic<int>& per_cu_cache = per_cu_caches[e->cfg.device_id % AZG_MAX_DEVICES];
+    std::atomic<size_t>& lds_cache = lds_caches[e->cfg.device_id % AZG_MAX_DEVICES];
     int per_cu = per_cu_cache.load(std::memory_order_relaxed);
-    if (per_cu < 0 || lds != lds_cache.load(std::memory_order_relaxed)) {
+    if (per_cu <= 0 || lds != lds_cache.load(std::memory_order_relaxed)) {
         hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (rc != hipSuccess) return rc;
         rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds);
