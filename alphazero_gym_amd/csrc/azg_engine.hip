@@ -281,7 +281,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
     {
         unsigned long long* st;
-        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 4 * 16, e->dev_allocs));
+        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 8 * 16, e->dev_allocs));   // (diagnostic builds: up to 8 waves per 16-tree group)
         e->P.stamps = st;
     }
     std::vector<double> sq(e->tab_n);
@@ -704,7 +704,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
-    size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 4;
+    size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 8;
     if (rows > max_rows) rows = max_rows;
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));

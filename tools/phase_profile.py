@@ -32,12 +32,18 @@ def main():
         e.search_resident()
     e.sync()
     print("kernel ms", e.last_search_ms())
-    rows = (B + 15) // 16 * 4
-    buf = np.zeros((rows, 16), np.uint64)
     lib = _native.lib()
+    name = C.create_string_buffer(256)
+    lib.azg_debug_kernel_name(C.c_void_p(e._h.value), name, C.c_size_t(256))
+    print("kernel", name.value.decode())
+    args = name.value.decode().split("<")[1].rstrip(">").split(",")
+    waves, groups = int(args[5]), int(args[6])             # search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>
+    rows = (B + 16 * groups - 1) // (16 * groups) * waves   # one row per wave
+    buf = np.zeros((max(rows, (B + 15) // 16 * 8), 16), np.uint64)
     lib.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
-    n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), rows)
-    assert n == rows
+    n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf))
+    assert n >= rows
+    buf = buf[:rows]
     names = ["barrier wait", "network (MLP)", "finish leaf + backup", "select/step/expand"]
     tot = buf[:, :4].sum(1).mean()
     for i, nm in enumerate(names):
