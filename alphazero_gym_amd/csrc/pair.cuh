@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PAIR_WALKER
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             TSTAMP(t2);
-            if (a.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, a.st, a.ts, a.cold, a.edge_W, a.action, a.tb, sim, sub, slot, a.gtree, my_parts, s_bhead);
+            if (a.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, a.st, a.ts, a.cold, a.edge_W, a.action, a.tb, sim, sub, slot, a.gtree, my_parts, s_bhead, s_sqrt);
             a.st.need_eval = false;
             TSTAMP(t3);
             TADD(0, t0, t1); TADD(1, t1, t2); TADD(2, t2, t3);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
 #endif
         STAMP(t_c);
         // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl & 15, gtree, my_parts, s_bhead);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl & 15, gtree, my_parts, s_bhead, s_sqrt);
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
         STAMP(t_d);

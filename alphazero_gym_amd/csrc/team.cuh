@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
 #ifdef AZG_STAMPS
         unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (the tree phases' own stamps: discarded here)
 #endif
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt);
         st.need_eval = false;
         if (k < P.n_sims) {
             __threadfence_block();

@@ -138,7 +138,10 @@ template <> struct TreeStore<TS_GLOBAL> {
     Rec* hot; unsigned short* child; float* prior;
     __device__ __forceinline__ int child_at(int p, const Rec&, int i, int Kp) const { return (int)child[p * Kp + i]; }
     __device__ __forceinline__ void child_append(int p, const Rec&, int K, int id, int&, bool writer, int Kp) const {
-        if (writer) { child[p * Kp + K] = (unsigned short)id; hot[p].n_child = (unsigned short)(K + 1); }
+        if (writer) {
+            child[p * Kp + K] = (unsigned short)id;
+            hot[p].n_child = (unsigned short)(K + 1);
+        }
     }
 };
 
@@ -155,9 +158,11 @@ __device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
 // MCTS.backprop (mcts.py:260-267), generic part: walks parent links from record j to the root, 16 levels at a time
 // (lane d = d-th record), fetches rewards / W in parallel, chains the discounted return serially (its rounding order
 // is part of the contract), then every lane updates its own record.
-template <bool CONT, int TLDS>
+// on_node(p): called (by all 16 lanes, p uniform) for every node whose statistics were updated here, after the update is stored
+// (the caller of backup_path looks after the nodes of the last 16 levels itself).
+template <bool CONT, int TLDS, typename F>
 __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int j, float V, int sub,
-                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv) {
+                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv, F&& on_node) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     while (true) {
         int mine = 0, cnt = 0, jj = j;
@@ -202,6 +207,11 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
             if (!(at_leaf && sub == 0)) mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
             ts.hot[mine] = mrec;
         }
+        if (!TLDS) __threadfence_block();
+        for (int d = 0; d < cnt; ++d) {
+            const int pn = __shfl(mine, d, 16);
+            if (!(at_leaf && d == 0)) on_node(pn);   // (a trace's leaf has no selection to refresh)
+        }
         if (hit_root) break;
         j = jj;
         at_leaf = false;
@@ -210,9 +220,9 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 
 // Backup of a trace whose path the descent left in the lanes: slot (depth & 15) holds the record id, its reward and W
 // (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
-template <bool CONT, int TLDS>
+template <bool CONT, int TLDS, typename F>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
-                                            double gamma, int D, int my_depth, int pid, double pr, double pW) {
+                                            double gamma, int D, int my_depth, int pid, double pr, double pW, F&& on_node) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
@@ -243,6 +253,6 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
     }
     if (D >= 16) {
         int j = __shfl(par, (D - 15) & 15, 16);   // parent of the shallowest record handled above
-        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv);
+        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv, on_node);
     }
 }

@@ -20,6 +20,129 @@ struct TreeState {
     int ptop;             // LDS trees: next free 4-byte unit of the child-list pool
 };
 
+// ---- the cached selection of a node ("best"): the child the next descent through the node will take.
+// The reference scores a node's children when a trace comes by (selectionUCT).  Between two visits of a node nothing its
+// scores depend on changes -- its own count and its children's counts / Q move only when a trace passes through it, and the
+// backup of that very trace is the last thing that touches them -- so the arg-max can just as well be taken right after the
+// backup and stored with the node: same inputs, same arithmetic, same winner.  The descent then only follows the stored
+// children (two LDS round trips per level instead of a dependent chain of child list, child records, division, arg-max), and
+// the scoring work moves into the backup, where the nodes of the path are all known at once and are scored side by side
+// instead of one after the other -- in discrete mode in ONE pass: two lanes per node (refresh_best_pairs).  Used in discrete mode
+// without epsilon-greedy selection.  Continuous mode keeps scoring on the way down: there a trace ends by widening a node, which
+// the descent never has to score but the backup would (2.6 scorings per step instead of 1.6), and the register-starved
+// kernels do not interleave the scorings: measured 1.74 ms against 1.65 ms at config C.
+// Where the field lives: continuous mode: `first` -- the only child while there is one, free from the second child on (LDS
+// trees keep longer lists in the pool, global trees in the child table); discrete mode: the winner's INDEX (0 .. A-1) in the
+// byte continuous mode uses for `cbase` (RecS / RecM) or in `pad` (RecL).
+template <bool CONT> __device__ __forceinline__ int rec_best(const RecS& h) { return CONT ? (int)h.first : (int)h.first + (int)h.cbase; }
+template <bool CONT> __device__ __forceinline__ int rec_best(const RecM& h) { return CONT ? (int)h.first : (int)h.first + (int)h.cbase; }
+template <bool CONT> __device__ __forceinline__ int rec_best(const RecL& h) { return CONT ? (int)h.first : (int)h.first + (int)h.pad; }
+template <bool CONT> __device__ __forceinline__ void set_best(RecS* r, const RecS& h, int c) {
+    if (CONT) r->first = (unsigned char)c; else r->cbase = (unsigned char)(c - (int)h.first);
+}
+template <bool CONT> __device__ __forceinline__ void set_best(RecM* r, const RecM& h, int c) {
+    if (CONT) r->first = (unsigned)c; else r->cbase = (unsigned)(c - (int)h.first);
+}
+template <bool CONT> __device__ __forceinline__ void set_best(RecL* r, const RecL& h, int c) {
+    if (CONT) r->first = (unsigned short)c; else r->pad = (unsigned char)(c - (int)h.first);
+}
+
+// selectionUCT's scores and arg-max for node p (record hp, K = hp.n_child >= 1 children): the chosen child's record, the same in
+// all 16 lanes of the tree.  pick >= 0: that child index instead of the arg-max (epsilon-greedy).
+template <int ENV, int TLDS, typename Rec>
+__device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TLDS>& ts, int p, const Rec& hp, int sub, const double* s_sqrt,
+                                            int pick) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    const int K = hp.n_child;
+    // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
+    // carry a count beyond the table, then the correctly rounded square root is computed in place
+    double sq;
+    if (CONT || (int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
+    else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
+    int win_c = 0;
+    if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
+        // the common case: all children fit one 16-lane row
+        const bool valid = sub < K;
+        // no branch around the loads: lanes beyond the last child score record 0 and are masked out of the arg-max
+        const int si = valid ? sub : 0;
+        int c = CONT ? ts.child_at(p, hp, si, P.Kp) : (int)hp.first + si;
+        if (!valid) c = 0;
+        Rec h = ts.hot[c];
+        double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
+        double U;
+        if (CONT) {
+            U = h.Q + P.c_uct * ratio;
+        } else {
+            float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+            U = h.Q + (double)pc * ratio;
+        }
+        if (pick >= 0) win_c = __shfl(c, pick, 16);
+        else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
+        else win_c = argmax16_payload(U, valid, sub, c);
+    } else {
+        double win_u = 0.0;
+        bool have = false;
+        for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
+            const int i = base + sub;
+            const bool valid = i < K;
+            int c = 0;
+            double U = 0.0;
+            if (valid) {
+                c = CONT ? ts.child_at(p, hp, i, P.Kp) : (int)hp.first + i;
+                Rec h = ts.hot[c];
+                double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
+                if (CONT) {
+                    U = h.Q + P.c_uct * ratio;
+                } else {
+                    float pc = ts.prior[c] * P.c_uct_f;
+                    U = h.Q + (double)pc * ratio;
+                }
+            }
+            int w;
+            if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
+            else w = argmax16(U, valid, sub);
+            if (w >= 0) {
+                int wc = __shfl(c, w, 16);
+                double wu = __shfl(U, w, 16);
+                if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
+            }
+        }
+    }
+    return win_c;
+}
+
+// Re-take the selection of node p after its statistics changed and store it with the node (lane 0 of the tree writes).
+template <int ENV, int TLDS>
+__device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<TLDS>& ts, int p, int sub, const double* s_sqrt) {
+    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    const Rec hp = ts.hot[p];
+    const int b = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, -1);
+    if (sub == 0) set_best<CONT>(&ts.hot[p], hp, b);
+}
+
+// Discrete mode (two actions): the nodes at depths d_hi, d_hi - 1, ... (at most 8 of them, not below d_lo) in ONE pass: lanes
+// 2i and 2i + 1 of the tree score the two children of the i-th node.  pid = the lanes' path slots (slot d & 15 holds depth d).
+template <int ENV, int TLDS>
+__device__ __forceinline__ void refresh_best_pairs(const KParams& P, const TreeStore<TLDS>& ts, int pid, int d_hi, int d_lo, int sub,
+                                                   const double* s_sqrt) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    const int dd = d_hi - (sub >> 1), a = sub & 1;
+    const bool on = dd >= d_lo;
+    const int p = __shfl(pid, (on ? dd : d_hi) & 15, 16);   // (depth 0's slot holds record 0)
+    const Rec hp = ts.hot[p];
+    double sq;
+    if ((int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
+    else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
+    const int c = (int)hp.first + a;
+    const Rec h = ts.hot[c];
+    const float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
+    const double U = h.Q + (double)pc * tree_div(sq, (double)((int)h.edge_n + 1));
+    const double o = dpp_f64<DPP_QUAD_XOR1>(U);   // the partner's score
+    // lane 2i decides: the first child unless the second is strictly larger (argmax2_payload's rule)
+    if (on && a == 0) set_best<false>(&ts.hot[p], hp, (int)hp.first + (U >= o ? 0 : 1));
+}
+
 // initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
 // workgroup (TPW trees per workgroup, tl = the tree's index in it)
 template <int ENV, int TLDS, int TPW = 16>
@@ -61,7 +184,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
-                                             const float* bhead) {
+                                             const float* bhead, const double* s_sqrt) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
@@ -122,11 +245,45 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 ts.hot[st.leaf].n_child = (decltype(ts.hot[st.leaf].n_child))A;
                 ts.hot[st.leaf].first = (decltype(ts.hot[st.leaf].first))k0;
             }
+            if (P.epsilon == 0.0) {
+                // the new node's own selection (refresh_best): its edges all start at Q = V with no visits, so its scores
+                // are V + (prior_a * c_uct as float32) * (sqrt(n + 1) / 1) -- a division by one is exact
+                if (A == 2) {
+                    const int nn = (int)ts.hot[st.leaf].node_n;   // 0, or the carried count of a reused root
+                    double sq;
+                    if (nn < P.tab_n) sq = s_sqrt[nn];
+                    else sq = __builtin_sqrt((double)(nn + 1));
+                    float prior_s = 0.0f;
+                    if (sub < A) prior_s = azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + sub) - mx) / sum;
+                    const float pc = prior_s * P.c_uct_f;
+                    const double U = (double)V + (double)pc * sq;
+                    const double o = dpp_f64<DPP_QUAD_XOR1>(U);
+                    if (sub == 0) set_best<false>(&ts.hot[st.leaf], make_edge<Rec>(0.0, 0), U >= o ? 0 : 1);   // (index relative to first)
+                } else {
+                    if (!TLDS) __threadfence_block();
+                    refresh_best<ENV, TLDS>(P, ts, st.leaf, sub, s_sqrt);
+                }
+            }
         }
     }
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
-        backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW);
+        const bool keep = !CONT && P.epsilon == 0.0;   // (cached selections: discrete mode, see rec_best)
+        backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
+                                [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); });
+        if constexpr (!CONT) {
+            if (keep) {
+                // the selections of the path's nodes, with their new statistics: depths D-1 .. max(0, D-15) are in the lanes' slots
+                // (anything deeper than 16 levels was refreshed by backup_from through the callback above)
+                const int D = st.path_D, lo = D > 15 ? D - 15 : 0;
+                if (!TLDS) __threadfence_block();
+                if (P.A == 2) {
+                    for (int d = D - 1; d >= lo; d -= 8) refresh_best_pairs<ENV, TLDS>(P, ts, st.pid, d, lo, sub, s_sqrt);
+                } else {
+                    for (int d = D - 1; d >= lo; --d) refresh_best<ENV, TLDS>(P, ts, __shfl(st.pid, d & 15, 16), sub, s_sqrt);
+                }
+            }
+        }
     }
 }
 
@@ -159,75 +316,19 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
             if (widen) break;
         }
-        int pick = -1;
-        if (P.epsilon != 0.0) {
-            // MCTS.epsilon_greedy (mcts.py:190-195)
-            azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
-            if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
-        }
-        // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
-        // carry a count beyond the table, then the correctly rounded square root is computed in place
-        double sq;
-        if (CONT || (int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
-        else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
-        int win_c = 0;
-        if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
-            // the common case: all children fit one 16-lane row
-            const bool valid = sub < K;
-            int c = 0;
-            double U = 0.0;
-            {
-                // no branch around the loads: lanes beyond the last child score record 0 and are masked out of the arg-max
-                const int si = valid ? sub : 0;
-                c = CONT ? ts.child_at(p, hp, si, P.Kp) : (int)hp.first + si;
-                if (!valid) c = 0;
-                Rec h = ts.hot[c];
-                double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
-                if (CONT) {
-                    U = h.Q + P.c_uct * ratio;
-                } else {
-                    float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
-                    U = h.Q + (double)pc * ratio;
-                }
+        if (CONT || P.epsilon != 0.0) {
+            // scored on the way down (continuous mode; epsilon-greedy selection, MCTS.epsilon_greedy mcts.py:190-195)
+            int pick = -1;
+            if (P.epsilon != 0.0) {
+                azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
+                if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
             }
-#ifdef AZG_STAMPS
-            U = U + 0.0 * (double)__shfl(c, 0, 16);   // consume the scores before the stamp
-#endif
-            STAMP(tl1);
-            STAMP_ADD(7, tl0, tl1);    // child records, priors, division, U
-            if (pick >= 0) win_c = __shfl(c, pick, 16);
-            else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
-            else win_c = argmax16_payload(U, valid, sub, c);
+            chosen = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, pick);
         } else {
-            double win_u = 0.0;
-            bool have = false;
-            for (int base = 0; base < K; base += 16) {   // children are scanned 16 at a time
-                const int i = base + sub;
-                const bool valid = i < K;
-                int c = 0;
-                double U = 0.0;
-                if (valid) {
-                    c = CONT ? ts.child_at(p, hp, i, P.Kp) : (int)hp.first + i;
-                    Rec h = ts.hot[c];
-                    double ratio = tree_div(sq, (double)((int)h.edge_n + 1));
-                    if (CONT) {
-                        U = h.Q + P.c_uct * ratio;
-                    } else {
-                        float pc = ts.prior[c] * P.c_uct_f;
-                        U = h.Q + (double)pc * ratio;
-                    }
-                }
-                int w;
-                if (pick >= 0) w = (pick >= base && pick < base + 16) ? pick - base : -1;
-                else w = argmax16(U, valid, sub);
-                if (w >= 0) {
-                    int wc = __shfl(c, w, 16);
-                    double wu = __shfl(U, w, 16);
-                    if (pick >= 0 || !have || wu > win_u) { win_c = wc; win_u = wu; have = true; }
-                }
-            }
+            chosen = rec_best<CONT>(hp);   // taken when the node's statistics last changed (refresh_best)
         }
-        chosen = win_c;
+        STAMP(tl1);
+        STAMP_ADD(7, tl0, tl1);    // the level's selection
         STAMP(tl2);
         Rec hc = ts.hot[chosen];
         if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * Q_WAVES, 1) void search_kernel_q(KParams P) {
 #endif
         for (int k = 0; k <= P.n_sims; ++k) {
             if (!q_wait(s_cnt, QC_PARTS(q), (unsigned)(k + 1))) return;
-            if (live) tree_phase_a<ENV, TS_LDS8, false, 8, 4>(P, st, ts, cold, edge_W, action, tb, k - 1, sub, tj, gtree, parts, s_bhead);
+            if (live) tree_phase_a<ENV, TS_LDS8, false, 8, 4>(P, st, ts, cold, edge_W, action, tb, k - 1, sub, tj, gtree, parts, s_bhead, s_sqrt);
             st.need_eval = false;
             if (k < P.n_sims) {
                 __threadfence_block();
