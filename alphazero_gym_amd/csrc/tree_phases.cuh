@@ -27,7 +27,7 @@ struct TreeState {
 // backup and stored with the node: same inputs, same arithmetic, same winner.  The descent then only follows the stored
 // children (two LDS round trips per level instead of a dependent chain of child list, child records, division, arg-max), and
 // the scoring work moves into the backup, where the nodes of the path are all known at once and are scored side by side
-// instead of one after the other -- in discrete mode in ONE pass: two lanes per node (refresh_best_pairs).  Used in discrete mode
+// instead of one after the other -- in discrete mode in ONE pass: a lane per node (refresh_best_own_slot).  Used in discrete mode
 // without epsilon-greedy selection.  Continuous mode keeps scoring on the way down: there a trace ends by widening a node, which
 // the descent never has to score but the backup would (2.6 scorings per step instead of 1.6), and the register-starved
 // kernels do not interleave the scorings: measured 1.74 ms against 1.65 ms at config C.
@@ -121,26 +121,24 @@ __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<T
     if (sub == 0) set_best<CONT>(&ts.hot[p], hp, b);
 }
 
-// Discrete mode (two actions): the nodes at depths d_hi, d_hi - 1, ... (at most 8 of them, not below d_lo) in ONE pass: lanes
-// 2i and 2i + 1 of the tree score the two children of the i-th node.  pid = the lanes' path slots (slot d & 15 holds depth d).
+// Discrete mode, two actions: every node of the path at once, each by the lane that holds its path slot (slot d & 15 = depth d,
+// record `pid`): the lane reads its node and the node's two children, scores both and stores the winner's index -- no
+// cross-lane traffic at all.  `mine`: the lane's slot holds a node of this path above the leaf.
 template <int ENV, int TLDS>
-__device__ __forceinline__ void refresh_best_pairs(const KParams& P, const TreeStore<TLDS>& ts, int pid, int d_hi, int d_lo, int sub,
-                                                   const double* s_sqrt) {
+__device__ __forceinline__ void refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt) {
     typedef typename TreeStore<TLDS>::Rec Rec;
-    const int dd = d_hi - (sub >> 1), a = sub & 1;
-    const bool on = dd >= d_lo;
-    const int p = __shfl(pid, (on ? dd : d_hi) & 15, 16);   // (depth 0's slot holds record 0)
+    const int p = mine ? pid : 0;
     const Rec hp = ts.hot[p];
     double sq;
     if ((int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
-    const int c = (int)hp.first + a;
-    const Rec h = ts.hot[c];
-    const float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
-    const double U = h.Q + (double)pc * tree_div(sq, (double)((int)h.edge_n + 1));
-    const double o = dpp_f64<DPP_QUAD_XOR1>(U);   // the partner's score
-    // lane 2i decides: the first child unless the second is strictly larger (argmax2_payload's rule)
-    if (on && a == 0) set_best<false>(&ts.hot[p], hp, (int)hp.first + (U >= o ? 0 : 1));
+    const int c0 = (int)hp.first;
+    const Rec h0 = ts.hot[c0], h1 = ts.hot[c0 + 1];
+    const float pc0 = ts.prior[c0] * P.c_uct_f, pc1 = ts.prior[c0 + 1] * P.c_uct_f;   // float32 products (NumPy >= 2 promotion)
+    const double U0 = h0.Q + (double)pc0 * tree_div(sq, (double)((int)h0.edge_n + 1));
+    const double U1 = h1.Q + (double)pc1 * tree_div(sq, (double)((int)h1.edge_n + 1));
+    // the first child unless the second is strictly larger (argmax2_payload's rule)
+    if (mine) set_best<false>(&ts.hot[p], hp, c0 + (U0 >= U1 ? 0 : 1));
 }
 
 // initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
@@ -278,7 +276,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 const int D = st.path_D, lo = D > 15 ? D - 15 : 0;
                 if (!TLDS) __threadfence_block();
                 if (P.A == 2) {
-                    for (int d = D - 1; d >= lo; d -= 8) refresh_best_pairs<ENV, TLDS>(P, ts, st.pid, d, lo, sub, s_sqrt);
+                    // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
+                    refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, st.my_depth >= lo && st.my_depth < D, s_sqrt);
                 } else {
                     for (int d = D - 1; d >= lo; --d) refresh_best<ENV, TLDS>(P, ts, __shfl(st.pid, d & 15, 16), sub, s_sqrt);
                 }
@@ -336,9 +335,11 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st.path_D += 1;
         p = chosen;
         hp = hc;
-        if (sub == (st.path_D & 15)) {   // only the slot's lane fetches the level's reward and W (used by backup_path)
+        if (sub == (st.path_D & 15)) {   // the level's path slot: its depth, its record, its reward and W (used by backup_path)
             st.my_depth = st.path_D; st.pid = chosen;
-            st.pr = cold[chosen].r; st.pW = edge_W[chosen];
+            // continuous mode (2-3 levels, a slow scored descent): fetched here, in the shadow of the level's LDS waits;
+            // discrete mode (8-9 levels of pointer chasing): all levels at once after the loop (measured both ways)
+            if (CONT) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
         }
         if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
             if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
@@ -355,6 +356,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
 #endif
     }
     if (!CONT && p != 0 && !hit_terminal) cp = cold[p];
+    if (!CONT && st.my_depth >= 1) { st.pr = cold[st.pid].r; st.pW = edge_W[st.pid]; }   // (consumed after the network phase: latency hidden)
     STAMP(tb1);
     STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {
