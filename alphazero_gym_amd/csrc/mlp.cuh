@@ -303,6 +303,19 @@ __device__ __forceinline__ float head_output(const f32x4* parts, const float* s_
     return total;
 }
 
+// outputs 0..3 of a tree at once (value + Normal parameters / action logits): one pass over the chunk partials, each component
+// summed exactly as head_output sums it (bias first, then the chunks in order)
+template <int NCH, int PSTR = 64>
+__device__ __forceinline__ f32x4 head_output4(const f32x4* parts, const float* s_bhead, int tl) {
+    f32x4 total = {s_bhead[0], s_bhead[1], s_bhead[2], s_bhead[3]};
+#pragma unroll
+    for (int w = 0; w < NCH; ++w) {
+        const f32x4 pv = parts[w * PSTR + tl];
+        total.x = total.x + pv.x; total.y = total.y + pv.y; total.z = total.z + pv.z; total.w = total.w + pv.w;
+    }
+    return total;
+}
+
 #define GMM_MAXC 5
 // DiagonalGMMPolicy head (policies.py:544-560) of one node from the raw network outputs: mu_c, sigma_c = exp(clamp(log_std_c)),
 // cumulative softmax(log_coeff) in component order.  d[15] = mu[5] | sigma[5] | cum[5] (fixed stride so that every index

@@ -187,7 +187,11 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
     if (st.need_eval) {
-        V = head_output<NCH, PSTR>(parts, bhead, tl, 0);
+        // discrete mode: outputs 0..3 (value, logits) in one pass over the partials; continuous mode keeps three separate
+        // sums (measured at config C: the one-pass form is 3 % slower there, at config B 10 % faster)
+        f32x4 out4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (!CONT) { out4 = head_output4<NCH, PSTR>(parts, bhead, tl); V = out4.x; }
+        else V = head_output<NCH, PSTR>(parts, bhead, tl, 0);
         if (CONT) {
             float mu, sg;
             float gd[15];
@@ -224,14 +228,16 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
         } else {
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
             const int A = P.A;
-            float mx = head_output<NCH, PSTR>(parts, bhead, tl, 1);
-            for (int a = 1; a < A; ++a) { float v = head_output<NCH, PSTR>(parts, bhead, tl, 1 + a); mx = v > mx ? v : mx; }
+            // (logits 1 .. 3 come with out4; further actions, should an environment have them, through head_output)
+            auto logit = [&](int a) { return a == 0 ? out4.y : (a == 1 ? out4.z : (a == 2 ? out4.w : head_output<NCH, PSTR>(parts, bhead, tl, 1 + a))); };
+            float mx = logit(0);
+            for (int a = 1; a < A; ++a) { float v = logit(a); mx = v > mx ? v : mx; }
             float sum = 0.0f;
-            for (int a = 0; a < A; ++a) sum = sum + azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + a) - mx);
+            for (int a = 0; a < A; ++a) sum = sum + azg_expf(logit(a) - mx);
             int k0 = st.nrec;
             st.nrec += A;
             if (sub < A) {
-                float prior_a = azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + sub) - mx) / sum;
+                float prior_a = azg_expf(logit(sub) - mx) / sum;
                 Rec h = make_edge<Rec>((double)V, st.leaf);
                 clear_pad(h);
                 ts.hot[k0 + sub] = h;
@@ -252,7 +258,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     if (nn < P.tab_n) sq = s_sqrt[nn];
                     else sq = __builtin_sqrt((double)(nn + 1));
                     float prior_s = 0.0f;
-                    if (sub < A) prior_s = azg_expf(head_output<NCH, PSTR>(parts, bhead, tl, 1 + sub) - mx) / sum;
+                    if (sub < A) prior_s = azg_expf(logit(sub) - mx) / sum;
                     const float pc = prior_s * P.c_uct_f;
                     const double U = (double)V + (double)pc * sq;
                     const double o = dpp_f64<DPP_QUAD_XOR1>(U);
