@@ -339,7 +339,7 @@ def main():
                              "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
                              ["search_kernel<0, 128, 1, 1, false, 4, 1>"], 0.26 * mlp_flops(4, [128, 128], 3),
-                             "tree-walk bound (9.2 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction", dev),
+                             "tree-walk bound (8-9 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction; selections are taken at backup time and stored with the nodes, the descent follows them", dev),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
                              ["ls_team_kernel<2, 1024, false, 1>"],
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
