@@ -350,8 +350,10 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
             if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
         }
-        if (CONT) cp = cold[p];   // Pendulum: a trace is 2-3 levels deep and the prefetch hides the one exposed global round trip;
-                                  // CartPole: 8-9 levels, issuing it at every level costs more than waiting once (measured)
+        // the node's env state for the step that follows if the trace leaves the tree here: requested at every level, the wave
+        // waits only for the last one (Pendulum: the whole cold record, its widening needs the cached policy too)
+        if (CONT) cp = cold[p];
+        else { cp.s[0] = cold[p].s[0]; cp.s[1] = cold[p].s[1]; cp.s[2] = cold[p].s[2]; cp.s[3] = cold[p].s[3]; }
         STAMP(tl4);
         STAMP_ADD(8, tl0, tl2);    // whole selection of a level (scores + arg-max)
         STAMP_ADD(9, tl2, tl3);    // chosen record
@@ -361,7 +363,6 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st_acc[12] += 1;
 #endif
     }
-    if (!CONT && p != 0 && !hit_terminal) cp = cold[p];
     if (!CONT && st.my_depth >= 1) { st.pr = cold[st.pid].r; st.pW = edge_W[st.pid]; }   // (consumed after the network phase: latency hidden)
     STAMP(tb1);
     STAMP_ADD(13, tb0, tb1);       // whole descent
