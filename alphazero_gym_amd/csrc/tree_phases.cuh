@@ -232,12 +232,16 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
             auto logit = [&](int a) { return a == 0 ? out4.y : (a == 1 ? out4.z : (a == 2 ? out4.w : head_output<NCH, PSTR>(parts, bhead, tl, 1 + a))); };
             float mx = logit(0);
             for (int a = 1; a < A; ++a) { float v = logit(a); mx = v > mx ? v : mx; }
-            float sum = 0.0f;
-            for (int a = 0; a < A; ++a) sum = sum + azg_expf(logit(a) - mx);
+            float sum = 0.0f, e_mine = 0.0f;   // e_mine: exp(logit - max) of the lane's own action (lanes 0 .. A-1)
+            for (int a = 0; a < A; ++a) {
+                const float e = azg_expf(logit(a) - mx);
+                sum = sum + e;
+                if (sub == a) e_mine = e;
+            }
             int k0 = st.nrec;
             st.nrec += A;
             if (sub < A) {
-                float prior_a = azg_expf(logit(sub) - mx) / sum;
+                float prior_a = e_mine / sum;
                 Rec h = make_edge<Rec>((double)V, st.leaf);
                 clear_pad(h);
                 ts.hot[k0 + sub] = h;
@@ -258,7 +262,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     if (nn < P.tab_n) sq = s_sqrt[nn];
                     else sq = __builtin_sqrt((double)(nn + 1));
                     float prior_s = 0.0f;
-                    if (sub < A) prior_s = azg_expf(logit(sub) - mx) / sum;
+                    if (sub < A) prior_s = e_mine / sum;
                     const float pc = prior_s * P.c_uct_f;
                     const double U = (double)V + (double)pc * sq;
                     const double o = dpp_f64<DPP_QUAD_XOR1>(U);
