@@ -27,7 +27,8 @@ struct __attribute__((aligned(16))) RecS {
     unsigned char n_child : 6;   // node: number of child edges (<= 16)
     unsigned char flags : 2;     // FLAG_EXPANDED | FLAG_TERMINAL
     unsigned char first;     // record of child edge 0 (discrete: the children are contiguous)
-    unsigned char cbase;     // continuous, n_child >= 2: the child list starts at pool[4 * cbase]
+    unsigned char cbase;     // continuous, n_child >= 2: the child list starts at pool[4 * cbase];
+                             // discrete: index of the node's cached selection among its children (tree_phases.cuh: rec_best)
 };
 #define POOL_UNITS(R) ((7 * ((R) - 1) + 8) / 9 + 1)
 // The same record for trees of 256..511 records (9-bit ids, counts < 2048): everything but Q packed into one 64-bit word.
@@ -55,7 +56,7 @@ struct __attribute__((aligned(8))) RecL {
     unsigned short n_child;
     unsigned short first;
     unsigned char flags;
-    unsigned char pad;
+    unsigned char pad;       // discrete: index of the node's cached selection (rec_best)
 };
 static_assert(sizeof(RecS) == 16, "RecS must be 16 bytes");
 static_assert(sizeof(RecL) == 24, "RecL must be 24 bytes");
