@@ -185,6 +185,30 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         assert forms == ([3] if eligible else [0]), "the search did not run as the walker + server pair"
 
 
+def test_deep_discrete_traces(native):
+    """CartPole, 2500 simulations with an exploration constant that finds the balancing line: traces 80+ levels deep, far beyond the
+    16 levels a tree's lanes hold at once, so the backup (and, in discrete mode, the re-scoring of the path's selections) continues
+    through the generic parent-link walk (trees of this size live in global memory).  Every record bit-exact against the oracle;
+    the depth is asserted."""
+    NS, B = 2500, 9
+    kw = dict(env_id=0, mode=0, n_trees=B, n_sims=NS, c_uct=5.0, gamma=1.0, num_actions=2, seed=8, tree_id_base=5)
+    desc = _capi.make_desc(4, [64, 64], 2, "relu")
+    blob = O.make_weights(12, 4, [64, 64], 2, scale=0.2)
+    roots = np.zeros((B, 4))
+    roots[:, 2] = np.linspace(-0.01, 0.01, B)
+    a = _run(native.HipEngine, kw, desc, blob, roots, None, sidx=2)
+    b = _run(O.OracleEngine, kw, desc, blob, roots, None, sidx=2)
+    _assert_same(a, b)
+    par, nrec = a[1]["parent"], a[1]["n_records"]
+    deepest = 0
+    for t in range(B):
+        depth = np.zeros(int(nrec[t]), np.int32)
+        for j in range(1, int(nrec[t])):
+            depth[j] = depth[par[t][j]] + 1
+        deepest = max(deepest, int(depth.max()))
+    assert deepest > 60, deepest
+
+
 @pytest.mark.parametrize("big", [False, True])
 def test_carried_root_counts_beyond_the_sqrt_table(native, big):
     """A reused root searched again and again without moving on (legal in the reference: act() twice on one state) carries a
