@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
-import oracle_lib as O  # noqa: E402  (make_weights only)
+from alphazero_gym_amd import synthetic as O  # noqa: E402  (make_weights)
 from alphazero_gym_amd import _capi, _native  # noqa: E402
 
 

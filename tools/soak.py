@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np  # noqa: E402
 
-import oracle_lib as O  # noqa: E402  (make_weights only)
+from alphazero_gym_amd import synthetic as O  # noqa: E402  (make_weights)
 from alphazero_gym_amd import _capi, _native  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100

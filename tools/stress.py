@@ -4,7 +4,7 @@ single-tree and single-simulation corner cases; checks the count invariant and p
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
-import oracle_lib as O
+from alphazero_gym_amd import synthetic as O
 from alphazero_gym_amd import _capi, _native
 def run(B, NS, hidden, env=2, mode=1, **kw):
     base = dict(env_id=env, mode=mode, n_trees=B, n_sims=NS, seed=5)
