@@ -59,37 +59,15 @@ class Agent(ABC):
         self.optimizer.step()
         return {key: float(value.detach()) if hasattr(value, "detach") else float(value) for key, value in loss_dict.items()}
 
-    @property
-    def action_dim(self) -> int:
-        return self.nn.action_dim
-
-    @property
-    def state_dim(self) -> int:
-        return self.nn.state_dim
-
-    @property
-    def n_hidden_layers(self) -> int:
-        return self.nn.n_hidden_layers
-
-    @property
-    def n_hidden_units(self) -> int:
-        return self.nn.n_hidden_units
-
-    @property
-    def n_rollouts(self) -> int:
-        return self.mcts.n_rollouts
-
-    @property
-    def learning_rate(self) -> float:
-        return self.optimizer.param_groups[0]["lr"]
-
-    @property
-    def c_uct(self) -> float:
-        return self.mcts.c_uct
-
-    @property
-    def gamma(self) -> float:
-        return self.mcts.gamma
+    # read-only views the run scripts log (agents.py:106-144): network shape from the policy, search settings from the MCTS object
+    action_dim = property(lambda self: self.nn.action_dim)
+    state_dim = property(lambda self: self.nn.state_dim)
+    n_hidden_layers = property(lambda self: self.nn.n_hidden_layers)
+    n_hidden_units = property(lambda self: self.nn.n_hidden_units)
+    n_rollouts = property(lambda self: self.mcts.n_rollouts)
+    c_uct = property(lambda self: self.mcts.c_uct)
+    gamma = property(lambda self: self.mcts.gamma)
+    learning_rate = property(lambda self: self.optimizer.param_groups[0]["lr"])
 
     def reset_mcts(self, root_state: np.ndarray) -> None:
         """agents.py:146-155"""
