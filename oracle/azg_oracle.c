@@ -54,6 +54,7 @@ typedef struct {
     float* lng[AZG_MAX_HIDDEN_LAYERS];   /* LayerNorm weight / bias, zero padded to hidp */
     float* lnb[AZG_MAX_HIDDEN_LAYERS];
     float* W[AZG_MAX_HIDDEN_LAYERS];  /* [hidp][kp] zero padded; kp = in_dim (layer 0) or hidp[l-1] */
+    float* Wp[AZG_MAX_HIDDEN_LAYERS]; /* the same numbers as [hidp/8][kp][8] in the order mlp_forward consumes them (k permuted) */
     float* b[AZG_MAX_HIDDEN_LAYERS];
     float* Wh;                 /* [n_out][hidp_last] */
     float* bh;
@@ -236,15 +237,21 @@ static void mlp_forward(const mlp_t* m, const float* obs, float* out) {
     for (int i = 0; i < kp; ++i) x[i] = i < m->in_dim ? obs[i] : 0.0f;
     for (int l = 0; l < m->n_layers; ++l) {
         int hp = m->hidp[l];
-        for (int n = 0; n < hp; ++n) {
-            float acc = m->b[l][n];
-            const float* w = m->W[l] + (size_t)n * kp;
-            if (l == 0) {
-                for (int k = 0; k < kp; ++k) acc = AZG_FMAF(w[k], x[k], acc);
-            } else {
-                for (int i = 0; i < kp; ++i) { int k = perm_k(i); acc = AZG_FMAF(w[k], x[k], acc); }
+        /* eight units at a time: each unit's sum is still its own k-ordered fma chain (same bits as one unit after the other);
+         * the eight independent chains keep the CPU's fma pipes busy (one 8-lane vfmadd per k when the compiler vectorises:
+         * per-lane IEEE fma, same bits).  hp is a multiple of 64. */
+        float xp[4096];
+        for (int i = 0; i < kp; ++i) xp[i] = x[l == 0 ? i : perm_k(i)];
+        for (int n0 = 0; n0 < hp; n0 += 8) {
+            float acc[8];
+            const float* w = m->Wp[l] + (size_t)n0 * kp;
+            for (int j = 0; j < 8; ++j) acc[j] = m->b[l][n0 + j];
+            for (int i = 0; i < kp; ++i) {
+                const float xv = xp[i];
+#pragma omp simd
+                for (int j = 0; j < 8; ++j) acc[j] = AZG_FMAF(w[(size_t)i * 8 + j], xv, acc[j]);
             }
-            h[n] = act_fn(m->act, acc);
+            for (int j = 0; j < 8; ++j) h[n0 + j] = act_fn(m->act, acc[j]);
         }
         if (m->layernorm) layer_norm(h, hp, m->hid[l], m->lng[l], m->lnb[l]);
         float* t = x; x = h; h = t;
@@ -325,7 +332,7 @@ static void free_tree(tree_t* t) {
 void azo_engine_destroy(azg_engine* e) {
     if (!e) return;
     if (e->trees) { for (int i = 0; i < e->cfg.n_trees; ++i) free_tree(&e->trees[i]); free(e->trees); }
-    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.b[l]); free(e->mlp.lng[l]); free(e->mlp.lnb[l]); }
+    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.Wp[l]); free(e->mlp.b[l]); free(e->mlp.lng[l]); free(e->mlp.lnb[l]); }
     free(e->mlp.Wh); free(e->mlp.bh); free(e->pw_need); free(e->roots); free(e->carry);
     free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
     free(e);
@@ -402,7 +409,7 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (need != n_floats) return fail(e, AZG_E_INVALID, "weight blob size mismatch");
     mlp_t* m = &e->mlp;
     m->layernorm = d->layernorm ? 1 : 0;
-    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(m->W[l]); free(m->b[l]); m->W[l] = NULL; m->b[l] = NULL; }
+    for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(m->W[l]); free(m->Wp[l]); free(m->b[l]); m->W[l] = NULL; m->Wp[l] = NULL; m->b[l] = NULL; }
     free(m->Wh); free(m->bh);
     m->n_layers = d->n_hidden; m->in_dim = d->in_dim; m->n_out = 1 + d->n_dist; m->act = d->activation;
     m->ls_min = d->log_std_min; m->ls_max = d->log_std_max;
@@ -419,6 +426,10 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         m->W[l] = (float*)calloc((size_t)hp * kp, 4);
         m->b[l] = (float*)calloc(hp, 4);
         for (int n = 0; n < h; ++n) memcpy(m->W[l] + (size_t)n * kp, p + (size_t)n * kt, sizeof(float) * kt);
+        m->Wp[l] = (float*)calloc((size_t)hp * kp, 4);
+        for (int n = 0; n < hp; ++n)
+            for (int i = 0; i < kp; ++i)
+                m->Wp[l][((size_t)(n / 8) * kp + i) * 8 + n % 8] = m->W[l][(size_t)n * kp + (l == 0 ? i : perm_k(i))];
         p += (size_t)h * kt;
         memcpy(m->b[l], p, sizeof(float) * h);
         p += h;

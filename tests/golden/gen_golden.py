@@ -3,6 +3,7 @@
 
     python tests/golden/gen_golden.py            # needs /root/reference; writes tests/golden/*.npz
     python tests/golden/gen_golden.py t7         # only the self-play tier
+    python tests/golden/gen_golden.py wide       # only t2_mlp_wide.npz (4x1024, 2x512), t3_full_rollouts.npz (n_rollouts = 200), t5_update.npz
 
 The reference (timoklein/alphazero-gym) is imported unmodified from /root/reference.  `gym`, `hydra`
 and `omegaconf` are not installed in this image; the reference's hot path only needs their names for
@@ -496,6 +497,90 @@ def run_t3():
     return out
 
 
+def run_t2_wide():
+    """T2 for the wide trunks: BASELINE config E's 4x1024 ELU network (policies.py:436-464: 1024-term dot products, torch's
+    blocked sgemm against the engine's k-ordered fma chains) and a 2x512 one, 256 observations each."""
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(2025))
+    for name, hidden in (("c1024x4", [1024] * 4), ("c512x2", [512, 512])):
+        blob = O.make_weights(34, 3, hidden, 2)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                          num_components=1, action_bound=2.0)
+        set_policy_weights(pol, blob, 3, hidden, 2)
+        th = rng.uniform(-np.pi, np.pi, 256); thd = rng.uniform(-8, 8, 256)
+        obs = np.stack([np.cos(th), np.sin(th), thd], 1).astype(np.float32)
+        x = torch.from_numpy(obs)
+        with torch.no_grad():
+            pol.eval()
+            mu, sigma, V = pol(x)
+        out[f"{name}_obs"] = obs
+        out[f"{name}_V"] = pol.predict_V(x).reshape(-1)
+        out[f"{name}_mu"] = mu.numpy().reshape(-1)
+        out[f"{name}_sigma"] = sigma.numpy().reshape(-1)
+    return out
+
+
+def _t3_pendulum_leg(hidden, roots, n_rollouts, K, seed=34):
+    """The reference's MCTSContinuous.search (mcts.py:656-702) with its real torch policy on every root; torch.normal patched to
+    the engine's noise of tree id = the root's index."""
+    blob = O.make_weights(34, 3, hidden, 2)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    set_policy_weights(pol, blob, 3, hidden, 2)
+    counts_l, Q_l, act_l, V_l = [], [], [], []
+    orig_normal = torch.normal
+    try:
+        for ti, root in enumerate(roots):
+            state = {"n": 0}
+
+            def fake_normal(mean, std, *a, **k):
+                state["n"] += 1
+                eps = O.normal(seed, ti, 0, state["n"])
+                return mean + std * np.float32(eps)
+
+            torch.normal = fake_normal
+            COUNTER["n"] = 0
+            env = PendulumEnv(state=root, version=1)
+            m = RM.MCTSContinuous(model=pol, n_rollouts=n_rollouts, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                                  V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
+            m.search(env)
+            s, actions, counts, Q, V = m.return_results("max_visit")
+            assert len(counts) == K, len(counts)
+            counts_l.append(np.asarray(counts, np.int32)); Q_l.append(np.array([np.asarray(q).reshape(-1)[0] for q in Q]))
+            act_l.append(np.asarray(actions, np.float32).reshape(-1)); V_l.append(float(np.asarray(V).reshape(-1)[0]))
+    finally:
+        torch.normal = orig_normal
+    return np.stack(counts_l), np.stack(Q_l), np.stack(act_l), np.array(V_l)
+
+
+def run_t3_full():
+    """T3 at the headline search size: n_rollouts = 200 (BASELINE configs C and E).  Roots are the engine's own synthetic roots
+    of global tree ids 0..15 (config C's first 16 trees, 2x256 ELU) and 0..3 (config E's, 4x1024 ELU) -- not hand-picked."""
+    out = {}
+    eng = O.OracleEngine(env_id=2, mode=1, n_trees=16, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1, kappa=0.5, seed=34)
+    roots = eng.synthetic_roots()
+    eng.close()
+    c, q, a, v = _t3_pendulum_leg([256, 256], roots, 200, 15)
+    out["c_roots"] = roots; out["c_counts"] = c; out["c_Q"] = q; out["c_actions"] = a; out["c_v_target"] = v
+    c, q, a, v = _t3_pendulum_leg([1024] * 4, roots[:4], 200, 15)
+    out["e_roots"] = roots[:4]; out["e_counts"] = c; out["e_Q"] = q; out["e_actions"] = a; out["e_v_target"] = v
+    return out
+
+
+def main_wide():
+    t5u = run_t5_update()
+    np.savez_compressed(os.path.join(HERE, "t5_update.npz"), **t5u)
+    print("t5 update", t5u["c_info"][-1].tolist(), t5u["da0c_info"][-1].tolist())
+    t2w = run_t2_wide()
+    np.savez_compressed(os.path.join(HERE, "t2_mlp_wide.npz"), **t2w)
+    print("t2 wide keys", len(t2w))
+    TIES["n"] = 0
+    t3f = run_t3_full()
+    assert TIES["n"] == 0, "t3 full: argmax tie occurred in the reference run"
+    np.savez_compressed(os.path.join(HERE, "t3_full_rollouts.npz"), **t3f)
+    print("t3 full c_counts[0]", t3f["c_counts"][0].tolist(), "e_counts[0]", t3f["e_counts"][0].tolist())
+
+
 def run_t4():
     """Agent level: the reference's DiscreteAgent.act / ContinuousAgent.act (agents.py:257-303, 492-537) on top of the
     T1 machinery (oracle-MLP evaluator, engine noise), built without hydra by filling the attributes __init__ would set."""
@@ -596,6 +681,66 @@ def run_t5():
     az = AlphaZeroLoss(policy_coeff=1.0, value_coeff=0.5, reduction="mean")
     d = az(logits, torch.softmax(torch.from_numpy(counts), dim=-1), vh2, torch.from_numpy(V))
     out["d_az"] = np.array([float(d[k]) for k in ("loss", "policy_loss", "value_loss")])
+    return out
+
+
+def run_t5_update():
+    """The reference's own optimiser steps: ContinuousAgent.update (agents.py:539-603) with A0CLossTuned (losses.py:431-500) and
+    DiscreteAgent.update (agents.py:319-392) with A0CLoss (the `counts += 1` branch), three consecutive
+    steps each on fixed minibatches with the reference's RMSprop settings (config/optimizer/RMSProp.yaml) and gradient clipping.
+    Agents are built without hydra by filling the attributes __init__ would set.  Stored: the minibatches, the loss dictionaries
+    of every step, the first step's gradients and the parameters after the third step."""
+    from alphazero.agent.agents import ContinuousAgent, DiscreteAgent
+    from alphazero.agent.losses import A0CLoss, A0CLossTuned
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(78))
+    hidden = [64, 64]
+    B, K, STEPS = 16, 5, 3
+
+    def flat(params, grads=False):
+        return np.concatenate([(q.grad if grads else q.data).detach().numpy().ravel() for q in params])
+
+    def drive(tag, ag, batches, keys):
+        infos, g0 = [], None
+        for i, b in enumerate(batches):
+            info = ag.update(tuple(np.copy(x) for x in b))
+            infos.append([info[k] for k in keys])
+            if i == 0:
+                g0 = flat(list(ag.nn.parameters()), grads=True)
+        out[f"{tag}_info"] = np.array(infos, np.float64)
+        out[f"{tag}_grad0"] = g0
+        out[f"{tag}_params"] = flat(list(ag.nn.parameters()))
+
+    def opt(pol):
+        return torch.optim.RMSprop(pol.parameters(), lr=0.001, momentum=0, weight_decay=0, alpha=0.9, eps=1e-10)
+
+    # continuous, A0CLossTuned
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    set_policy_weights(pol, O.make_weights(21, 3, hidden, 2), 3, hidden, 2)
+    batches = [(rng.uniform(-1, 1, (B, 3)).astype(np.float32), rng.uniform(-1.9, 1.9, (B, K)).astype(np.float32),
+                rng.integers(1, 9, (B, K)).astype(np.float32), rng.uniform(-1, 0, (B, K, 1)), rng.uniform(-1, 0, B)) for _ in range(STEPS)]
+    ag = object.__new__(ContinuousAgent)
+    ag.nn = pol; ag.device = torch.device("cpu"); ag.clip = 0.5; ag.optimizer = opt(pol)
+    ag.loss = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0.5, device="cpu")
+    drive("c", ag, batches, ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss"))
+    out["c_alpha"] = np.array(float(ag.loss.alpha))
+    for i, name in enumerate(("states", "actions", "counts", "Qs", "V")):
+        out[f"c_{name}"] = np.stack([b[i] for b in batches])
+    # discrete, AlphaZeroLoss and A0CLoss
+    dbatches = [(rng.uniform(-1, 1, (B, 4)).astype(np.float32), np.tile(np.arange(2, dtype=np.float32), (B, 1)),
+                 rng.integers(0, 20, (B, 2)).astype(np.float32), rng.uniform(0, 10, (B, 2)), rng.uniform(0, 10, B)) for _ in range(STEPS)]
+    for i, name in enumerate(("states", "actions", "counts", "Qs", "V")):
+        out[f"d_{name}"] = np.stack([b[i] for b in dbatches])
+    # (DiscreteAgent.update with AlphaZeroLoss cannot be captured: agents.py:380-381 hands the Categorical that DiscretePolicy.forward
+    #  returns to F.cross_entropy, which raises TypeError in the reference itself; that loss is pinned on logits by run_t5)
+    for tag, loss, keys in (("da0c", A0CLoss(tau=0.1, policy_coeff=1, alpha=1, value_coeff=1, reduction="mean"),
+                             ("loss", "policy_loss", "entropy_loss", "value_loss")),):
+        pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu", num_actions=2)
+        set_policy_weights(pol, O.make_weights(22, 4, hidden, 2), 4, hidden, 2)
+        ag = object.__new__(DiscreteAgent)
+        ag.nn = pol; ag.device = torch.device("cpu"); ag.clip = 0; ag.optimizer = opt(pol); ag.loss = loss
+        drive(tag, ag, dbatches, keys)
     return out
 
 
@@ -794,6 +939,8 @@ def main_t7():
 def main():
     if sys.argv[1:] == ["t7"]:   # only the self-play tier (the other fixtures are left untouched)
         return main_t7()
+    if sys.argv[1:] == ["wide"]:   # only the wide-network T2 cases and the n_rollouts = 200 T3 legs
+        return main_wide()
     for name, case in T1_CASES.items():
         TIES["n"] = 0
         res = run_t1(case)
@@ -818,6 +965,7 @@ def main():
     print("t6", t6["slots"][-1].tolist(), t6["batches"].tolist())
     print("t3 ties", TIES["n"], "c_counts[0]", t3["c_counts"][0].tolist(), "d_counts", t3["d_counts"].tolist())
     main_t7()
+    main_wide()
 
 if __name__ == "__main__":
     main()

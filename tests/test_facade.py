@@ -170,38 +170,114 @@ def test_weights_are_resynced_after_an_optimiser_step(backend):
     assert v0 != v1 and abs(v1 - expect) < 1e-5
 
 
-def test_training_step_matches_reference_losses():
+def _training_step_matches_reference_losses(device):
+    """T5: get_train_data + the three losses on `device` against what the reference computed (torch CPU) on the same batches."""
     z = np.load(os.path.join(P.GOLDEN, "t5_training.npz"))
+    T = lambda k: torch.from_numpy(z[k]).to(device)   # noqa: E731
+    N = lambda t: t.detach().cpu().numpy()            # noqa: E731
     pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
                       num_components=1, action_bound=2.0)
     load_blob(pol, O.make_weights(21, 3, [64, 64], 2))
-    lp, ent, vh = pol.get_train_data(torch.from_numpy(z["c_states"]), torch.from_numpy(z["c_actions"]))
-    np.testing.assert_allclose(lp.detach().numpy(), z["c_log_probs"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ent.detach().numpy(), z["c_entropy"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(vh.detach().numpy(), z["c_V_hat"], rtol=1e-5, atol=1e-5)
+    pol = pol.to(device)
+    lp, ent, vh = pol.get_train_data(T("c_states"), T("c_actions"))
+    np.testing.assert_allclose(N(lp), z["c_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(ent), z["c_entropy"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(vh), z["c_V_hat"], rtol=1e-5, atol=1e-5)
     d = A0CLoss(tau=0.1, policy_coeff=0.1, alpha=0.5, value_coeff=1, reduction="mean")(
-        log_probs=lp, counts=torch.from_numpy(z["c_counts"]), entropy=ent, V=torch.from_numpy(z["c_V"]), V_hat=vh)
+        log_probs=lp, counts=T("c_counts"), entropy=ent, V=T("c_V"), V_hat=vh)
     np.testing.assert_allclose([float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss")], z["c_a0c"], rtol=1e-5)
-    lt = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0, device="cpu")
-    d = lt(log_probs=lp, counts=torch.from_numpy(z["c_counts"]), entropy=ent, V=torch.from_numpy(z["c_V"]), V_hat=vh)
+    lt = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0, device=device)
+    d = lt(log_probs=lp, counts=T("c_counts"), entropy=ent, V=T("c_V"), V_hat=vh)
     got = [float(d[k]) for k in ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss")] + [float(lt.alpha)]
     np.testing.assert_allclose(got, z["c_a0c_tuned"], rtol=1e-5)
     gm = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
                      num_components=2, action_bound=2.0)
     load_blob(gm, O.make_weights(23, 3, [64, 64], 6))
-    lp, ent, vh = gm.get_train_data(torch.from_numpy(z["c_states"]), torch.from_numpy(z["c_actions"]))
-    np.testing.assert_allclose(lp.detach().numpy(), z["g_log_probs"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ent.detach().numpy(), z["g_entropy"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(vh.detach().numpy(), z["g_V_hat"], rtol=1e-5, atol=1e-5)
+    gm = gm.to(device)
+    lp, ent, vh = gm.get_train_data(T("c_states"), T("c_actions"))
+    np.testing.assert_allclose(N(lp), z["g_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(ent), z["g_entropy"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(vh), z["g_V_hat"], rtol=1e-5, atol=1e-5)
     pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=2)
     load_blob(pol, O.make_weights(22, 4, [64, 64], 2))
-    lp, ent, vh = pol.get_train_data(torch.from_numpy(z["d_states"]), torch.from_numpy(z["d_actions"]))
-    np.testing.assert_allclose(lp.detach().numpy(), z["d_log_probs"], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ent.detach().numpy(), z["d_entropy"], rtol=1e-5, atol=1e-5)
-    dist, vh2 = pol(torch.from_numpy(z["d_states"]))
-    d = AlphaZeroLoss(1.0, 0.5, "mean")(dist.logits if False else pol._get_dist_params(torch.from_numpy(z["d_states"]))[0],
-                                        torch.softmax(torch.from_numpy(z["d_counts"]), dim=-1), vh2, torch.from_numpy(z["d_V"]))
+    pol = pol.to(device)
+    lp, ent, vh = pol.get_train_data(T("d_states"), T("d_actions"))
+    np.testing.assert_allclose(N(lp), z["d_log_probs"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N(ent), z["d_entropy"], rtol=1e-5, atol=1e-5)
+    dist, vh2 = pol(T("d_states"))
+    d = AlphaZeroLoss(1.0, 0.5, "mean")(pol._get_dist_params(T("d_states"))[0], torch.softmax(T("d_counts"), dim=-1), vh2, T("d_V"))
     np.testing.assert_allclose([float(d[k]) for k in ("loss", "policy_loss", "value_loss")], z["d_az"], rtol=1e-5)
+
+
+def test_training_step_matches_reference_losses():
+    _training_step_matches_reference_losses("cpu")
+
+
+@pytest.mark.gpu
+def test_training_step_matches_reference_losses_on_the_device():
+    """SURVEY 8 f2 on PyTorch-ROCm: the same T5 assertions with parameters, batches and losses on cuda:0."""
+    _training_step_matches_reference_losses("cuda")
+
+
+def _bare_agent(cls, pol, loss, clip, device):
+    """An agent without its MCTS half (update() needs nn / loss / optimizer / clip / device only): the attributes __init__ sets,
+    with the reference's RMSprop settings (config/optimizer/RMSProp.yaml)."""
+    ag = object.__new__(cls)
+    ag.device = torch.device(device)
+    ag.nn = pol.to(ag.device)
+    ag.loss = loss
+    ag.clip = clip
+    ag.optimizer = torch.optim.RMSprop(ag.nn.parameters(), lr=0.001, momentum=0, weight_decay=0, alpha=0.9, eps=1e-10)
+    return ag
+
+
+def _optimiser_steps_match_the_reference(device):
+    """tests/golden/t5_update.npz (gen_golden.py run_t5_update): three consecutive ContinuousAgent.update steps with A0CLossTuned
+    (agents.py:539-603, losses.py:431-500; gradient clipping 0.5) and three DiscreteAgent.update steps with A0CLoss (the
+    `counts += 1` branch, agents.py:360-375) as the reference ran them: every step's loss dictionary, the first step's gradients
+    and the parameters after the third step.  RMSprop's first steps move every weight by about lr / sqrt(1 - alpha) whatever the
+    gradient's size, so a weight whose gradient is within rounding of zero may legitimately land on the other side: the
+    parameter check allows one such entry per thousand (there is none on the CPU)."""
+    z = np.load(os.path.join(P.GOLDEN, "t5_update.npz"))
+
+    def drive(ag, tag, keys):
+        infos = []
+        for i in range(z[f"{tag}_info"].shape[0]):
+            pre = "c" if tag == "c" else "d"
+            batch = tuple(np.copy(z[f"{pre}_{n}"][i]) for n in ("states", "actions", "counts", "Qs", "V"))
+            info = ag.update(batch)
+            infos.append([info[k] for k in keys])
+            if i == 0:
+                g0 = np.concatenate([q.grad.detach().cpu().numpy().ravel() for q in ag.nn.parameters()])
+                np.testing.assert_allclose(g0, z[f"{tag}_grad0"], rtol=2e-4, atol=2e-7)
+        np.testing.assert_allclose(np.array(infos), z[f"{tag}_info"], rtol=2e-5, atol=1e-6)
+        got = np.concatenate([q.detach().cpu().numpy().ravel() for q in ag.nn.parameters()])
+        close = np.isclose(got, z[f"{tag}_params"], rtol=0, atol=2e-5)
+        assert close.mean() > 0.999 and np.abs(got - z[f"{tag}_params"]).max() < 0.03, (close.mean(), np.abs(got - z[f"{tag}_params"]).max())
+        return close.all()
+
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    load_blob(pol, O.make_weights(21, 3, [64, 64], 2))
+    loss = A0CLossTuned(action_dim=1, alpha_init=1, lr=0.001, tau=0.1, policy_coeff=0.1, value_coeff=1, reduction="mean", grad_clip=0.5, device=device)
+    ag = _bare_agent(ContinuousAgent, pol, loss, 0.5, device)
+    exact_c = drive(ag, "c", ("loss", "policy_loss", "entropy_loss", "value_loss", "alpha_loss"))
+    np.testing.assert_allclose(float(loss.alpha), float(z["c_alpha"]), rtol=1e-6)
+    pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=2)
+    load_blob(pol, O.make_weights(22, 4, [64, 64], 2))
+    ag = _bare_agent(DiscreteAgent, pol, A0CLoss(tau=0.1, policy_coeff=1, alpha=1, value_coeff=1, reduction="mean"), 0, device)
+    exact_d = drive(ag, "da0c", ("loss", "policy_loss", "entropy_loss", "value_loss"))
+    return exact_c and exact_d
+
+
+def test_optimiser_steps_match_the_reference():
+    assert _optimiser_steps_match_the_reference("cpu")   # same torch, same device as the reference run: every parameter within 2e-5
+
+
+@pytest.mark.gpu
+def test_optimiser_steps_match_the_reference_on_the_device():
+    """The training step where it runs in production: parameters, batches, losses and RMSprop state on cuda:0 (PyTorch-ROCm)."""
+    _optimiser_steps_match_the_reference("cuda")
 
 
 def test_replay_buffer_fifo_and_last_batch_rule():

@@ -238,10 +238,19 @@ def test_terminal_root_raises(native):
     e.close()
 
 
+def _assert_block_identical(r, d, ro, do, lo, hi):
+    """Every result row and every tree record of trees [lo, hi): HIP engine (r, d: whole batch) against the oracle's block."""
+    for k in ro:
+        np.testing.assert_array_equal(ro[k], r[k][lo:hi], err_msg=f"{k} trees {lo}..{hi}")
+    for k in do:
+        np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=f"{k} trees {lo}..{hi}")
+
+
 @pytest.mark.parametrize("B", [4096, 8192 + 40])
 def test_full_size_properties(native, B):
-    """BASELINE config C (Pendulum-v1, 4096 trees, n_sims 200, 2x256 elu): size-independent invariants
-    + a seeded subset bit-exact against the oracle.  The larger, ragged batch takes the 8-wave / 32-tree workgroups."""
+    """BASELINE config C (Pendulum-v1, 4096 trees, n_sims 200, 2x256 elu; mcts.py:656-702): size-independent invariants
+     on every tree, and EVERY record of EVERY tree (results + whole tree dump) bit-exact against the oracle.
+    The larger, ragged batch takes the 8-wave / 32-tree workgroups."""
     NS = 200
     kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     desc = _capi.make_desc(3, [256, 256], 2, "elu")
@@ -251,28 +260,21 @@ def test_full_size_properties(native, B):
     roots = e.synthetic_roots()
     e.search(roots)
     r, d = e.results(), e.dump_tree()
+    e.close()
     assert (r["counts"].sum(1) == NS).all()                       # sum of root counts == n_sims
     assert (r["n_children"] == 15).all()                          # ceil(sqrt(200)) children at the root
     assert (d["n_records"] == NS + 1).all()                       # one new node per trace
     assert (d["node_n"][:, 0] == NS).all()
     # node.n == sum of child edge counts, for every node of every tree
-    for t in range(0, B, 257):
-        par, en, nn = d["parent"][t], d["edge_n"][t], d["node_n"][t]
-        acc = np.zeros_like(nn)
-        np.add.at(acc, par[1:NS + 1], en[1:NS + 1])
-        np.testing.assert_array_equal(acc[:NS + 1], nn[:NS + 1])
-    sel = np.unique(np.concatenate([np.arange(0, B, 128 * (B // 4096)), [B - 1]]))
-    # same global tree ids -> same noise: run the subset one engine per tree id
-    for i, t in enumerate(sel):
-        oo = O.OracleEngine(**dict(kw, n_trees=1, tree_id_base=int(t)))
-        oo.set_weights(desc, blob)
-        oo.search(roots[t:t + 1])
-        ro, do = oo.results(), oo.dump_tree()
-        np.testing.assert_array_equal(ro["counts"][0], r["counts"][t])
-        np.testing.assert_array_equal(ro["Q"][0], r["Q"][t])
-        np.testing.assert_array_equal(do["edge_W"][0], d["edge_W"][t])
-        oo.close()
-    e.close()
+    acc = np.zeros_like(d["node_n"])
+    rows = np.repeat(np.arange(B), NS)
+    np.add.at(acc, (rows, d["parent"][:, 1:NS + 1].ravel()), d["edge_n"][:, 1:NS + 1].ravel())
+    np.testing.assert_array_equal(acc[:, :NS + 1], d["node_n"][:, :NS + 1])
+    # the whole batch on the oracle (same global tree ids -> same noise), in blocks so that its trees stay cache-sized
+    for lo in range(0, B, 1024):
+        hi = min(B, lo + 1024)
+        ro, do = _oracle_block(kw, desc, blob, roots, lo, hi)
+        _assert_block_identical(r, d, ro, do, lo, hi)
 
 
 def _tree_invariants(r, d, NS, trees):
@@ -298,7 +300,8 @@ def _oracle_block(kw, desc, blob, roots, lo, hi):
 
 def test_config_b_full_size(native):
     """BASELINE config B (CartPole-v1 discrete, 4096 trees, n_sims 100, 2x128 relu) at size: count invariants on every tree (terminal
-    leaves included: a trace that ends in a terminal node creates no record) and two blocks of trees bit-exact against the oracle."""
+    leaves included: a trace that ends in a terminal node creates no record) and every record of all 4096 trees bit-exact
+    against the oracle (mcts.py:418-462)."""
     NS, B = 100, 4096
     kw = dict(env_id=0, mode=0, n_trees=B, n_sims=NS, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
     desc = _capi.make_desc(4, [128, 128], 2, "relu")
@@ -313,25 +316,22 @@ def test_config_b_full_size(native):
     assert (r["counts"].sum(1) == NS).all() and (r["n_children"] == 2).all()
     assert (d["node_n"][:, 0] == NS).all()
     assert (d["n_records"] <= 1 + 2 * (NS + 1)).all() and (d["n_records"] % 2 == 1).all()   # the root + two edges per expanded node
-    for t in range(0, B, 97):                                     # node.n == sum of child edge counts unless the node is terminal
+    for t in range(B):                                            # node.n == sum of child edge counts unless the node is terminal
         n = int(d["n_records"][t])
         par, en, nn, fl = d["parent"][t][:n], d["edge_n"][t][:n], d["node_n"][t][:n], d["node_flags"][t][:n]
         acc = np.zeros_like(nn)
         np.add.at(acc, par[1:], en[1:])
         inner = (fl & 2) == 0                                     # (FLAG_TERMINAL = 2: visits of a terminal node stop there)
         np.testing.assert_array_equal(acc[inner], nn[inner])
-    for lo in (0, B - 48):
-        ro, do = _oracle_block(kw, desc, blob, roots, lo, lo + 48)
-        for k in ("counts", "Q", "v_target"):
-            np.testing.assert_array_equal(ro[k], r[k][lo:lo + 48], err_msg=k)
-        for k in ("edge_n", "edge_W", "node_n", "parent"):
-            np.testing.assert_array_equal(do[k], d[k][lo:lo + 48], err_msg=k)
+    for lo in range(0, B, 1024):                                  # every record of every tree against the oracle
+        ro, do = _oracle_block(kw, desc, blob, roots, lo, lo + 1024)
+        _assert_block_identical(r, d, ro, do, lo, lo + 1024)
 
 
 def test_config_e_full_size_lockstep(native):
     """BASELINE config E per GPU (Pendulum-v1, 1024 trees, n_sims 200, 4x1024 ELU: mcts.py:656-702 at E's tree sizes) on the
     lock-step path (by default the persistent team kernel: 201 simulation steps in one launch).  Size-independent invariants on
-    every tree + 24 trees (both ends and the middle of the batch) bit-exact against the oracle: counts, Q, W, parents."""
+    every tree + every record of all 1024 trees bit-exact against the oracle (results and whole tree dumps)."""
     NS, B = 200, 1024
     kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     desc = _capi.make_desc(3, [1024] * 4, 2, "elu")
@@ -344,17 +344,14 @@ def test_config_e_full_size_lockstep(native):
     ms = e.last_search_ms()
     e.close()
     assert (r["n_children"] == 15).all()
-    _tree_invariants(r, d, NS, range(0, B, 61))
+    _tree_invariants(r, d, NS, range(B))
     depth = np.zeros((B, NS + 1), np.int32)
     for j in range(1, NS + 1):
         depth[:, j] = depth[np.arange(B), d["parent"][:, j]] + 1
     assert depth.max() >= 4, depth.max()                          # real trees: several levels below the root
-    for lo, hi in ((0, 8), (508, 516), (B - 8, B)):
-        ro, do = _oracle_block(kw, desc, blob, roots, lo, hi)
-        for k in ("counts", "Q", "actions", "v_target", "n_children"):
-            np.testing.assert_array_equal(ro[k], r[k][lo:hi], err_msg=k)
-        for k in do:
-            np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=k)
+    for lo in range(0, B, 256):                                   # all 1024 trees (the oracle streams 12.6 MB of weights per evaluation:
+        ro, do = _oracle_block(kw, desc, blob, roots, lo, lo + 256)   # about a minute on 16 host threads)
+        _assert_block_identical(r, d, ro, do, lo, lo + 256)
     assert ms < 40.0, f"config E search took {ms:.1f} ms (measured 16.6 ms in round 1)"
 
 

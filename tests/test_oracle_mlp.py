@@ -87,8 +87,35 @@ def _mlp_matches_torch_policies(engine_cls):
         np.testing.assert_allclose(d, z[f"{name}_pi"], atol=TOL, rtol=TOL)
 
 
+def _wide_mlp_matches_torch_policies(engine_cls):
+    """T2, wide trunks (tests/golden/gen_golden.py run_t2_wide): BASELINE config E's 4x1024 ELU network and a 2x512 one,
+    the reference's torch policy (policies.py:436-464) against the engine's k-ordered fp32 chains, 256 observations, 1e-5."""
+    z = np.load(os.path.join(P.GOLDEN, "t2_mlp_wide.npz"))
+    twin = None if engine_cls is O.OracleEngine else O.OracleEngine
+    for name, hidden in (("c1024x4", [1024] * 4), ("c512x2", [512, 512])):
+        kw = dict(env_id=2, mode=1, n_trees=1, n_sims=2, c_uct=0.05, gamma=1.0)
+        e = _Checked(engine_cls(**kw), twin(**kw) if twin else None)
+        e.set_weights(_capi.make_desc(3, hidden, 2, "elu"), O.make_weights(34, 3, hidden, 2))
+        v, d, _ = e.mlp_eval(z[f"{name}_obs"])
+        np.testing.assert_allclose(v, z[f"{name}_V"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 0], z[f"{name}_mu"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(d[:, 1], z[f"{name}_sigma"], atol=TOL, rtol=TOL)
+
+
 def test_mlp_matches_torch_policies():
     _mlp_matches_torch_policies(O.OracleEngine)
+
+
+def test_wide_mlp_matches_torch_policies():
+    _wide_mlp_matches_torch_policies(O.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_hip_wide_mlp_matches_torch_policies():
+    """Config E's network on the device (azg_mlp_eval) against the reference's torch policy, and HIP == oracle bit for bit."""
+    from alphazero_gym_amd import _native
+    _native.lib()
+    _wide_mlp_matches_torch_policies(_native.HipEngine)
 
 
 @pytest.mark.gpu
@@ -134,6 +161,38 @@ def test_hip_end_to_end_against_reference_with_torch_policy():
     from alphazero_gym_amd import _native
     _native.lib()
     _end_to_end(_native.HipEngine)
+
+
+def _end_to_end_full_rollouts(engine_cls):
+    """T3 at the headline search size (tests/golden/gen_golden.py run_t3_full): the reference's MCTSContinuous.search
+    (mcts.py:656-702) with n_rollouts = 200 and its real torch policy on the first 16 synthetic roots of config C (2x256 ELU) and
+    the first 4 of config E (4x1024 ELU): visit counts identical on every tree, Q / actions / value target within 1e-5."""
+    z = np.load(os.path.join(P.GOLDEN, "t3_full_rollouts.npz"))
+    for tag, hidden in (("c", [256, 256]), ("e", [1024] * 4)):
+        roots = z[f"{tag}_roots"]
+        e = engine_cls(env_id=2, mode=1, n_trees=len(roots), n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1, kappa=0.5, seed=34)
+        np.testing.assert_array_equal(e.synthetic_roots(), roots)      # the fixture's roots are the engine's own synthetic roots
+        e.set_weights(_capi.make_desc(3, hidden, 2, "elu"), O.make_weights(34, 3, hidden, 2))
+        e.search(roots)
+        r = e.results()
+        e.close()
+        assert (r["n_children"] == 15).all()
+        for i in range(len(roots)):
+            np.testing.assert_array_equal(r["counts"][i], z[f"{tag}_counts"][i], err_msg=f"{tag} tree {i}")
+            np.testing.assert_allclose(r["Q"][i], z[f"{tag}_Q"][i], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(r["actions"][i], z[f"{tag}_actions"][i], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(r["v_target"][i], z[f"{tag}_v_target"][i], atol=TOL, rtol=TOL)
+
+
+def test_end_to_end_full_rollouts_against_reference_with_torch_policy():
+    _end_to_end_full_rollouts(O.OracleEngine)
+
+
+@pytest.mark.gpu
+def test_hip_end_to_end_full_rollouts_against_reference_with_torch_policy():
+    from alphazero_gym_amd import _native
+    _native.lib()
+    _end_to_end_full_rollouts(_native.HipEngine)
 
 
 def _gmm_end_to_end(engine_cls):
