@@ -93,8 +93,8 @@ def _ptr(a, ctype):
 
 
 SYMBOLS = [
-    "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_search_index", "search",
-    "results", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
+    "abi_version", "engine_create", "engine_destroy", "last_error", "set_weights", "set_weights_device", "set_search_index", "search",
+    "results", "results_resident", "root_children", "root_eval", "dump_tree", "max_children", "max_records", "env_state_dim", "obs_dim",
     "synthetic_roots", "last_search_ms", "upload_roots", "search_resident", "sync",
     "selfplay_begin", "selfplay_begin_ex", "selfplay_step", "selfplay_row_len", "selfplay_rows", "selfplay_stats",
     "selfplay_ring", "selfplay_rows_device", "mlp_eval",
@@ -114,6 +114,8 @@ def bind(lib, prefix):
     f["last_error"].argtypes = [vp]
     f["last_error"].restype = C.c_char_p
     f["set_weights"].argtypes = [vp, C.POINTER(AzgMlpDesc), C.POINTER(C.c_float), C.c_size_t]
+    f["set_weights_device"].argtypes = [vp, C.POINTER(AzgMlpDesc), C.c_void_p, C.c_size_t]
+    f["results_resident"].argtypes = [vp] + [C.POINTER(C.c_void_p)] * 5
     f["set_search_index"].argtypes = [vp, C.c_uint32]
     f["search"].argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     f["results"].argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -141,10 +143,11 @@ def bind(lib, prefix):
     return f
 
 
-def policy_blob(policy):
-    """Flatten a torch policy into (AzgMlpDesc, float32 blob) in state_dict order.  Works for this package's policies
-    and for the reference's DiscretePolicy / DiagonalNormalPolicy objects alike (same attribute names:
-    trunk, value_head, dist_head, hidden_dimensions, state_dim; alphazero/network/policies.py:101-120, 238-259)."""
+def policy_tensors(policy):
+    """(AzgMlpDesc, [tensors in blob order]) of a torch policy: per trunk layer weight, bias (, LayerNorm weight, bias), then the
+    value head and the distribution head (= state_dict order).  Works for this package's policies and for the reference's
+    DiscretePolicy / DiagonalNormalPolicy objects alike (same attribute names: trunk, value_head, dist_head, hidden_dimensions,
+    state_dim; alphazero/network/policies.py:101-120, 238-259)."""
     hidden = list(policy.hidden_dimensions)
     linears, norms, acts = [], [], set()
     for mod in policy.trunk:
@@ -173,14 +176,20 @@ def policy_blob(policy):
     desc.log_std_max = float(getattr(policy, "log_param_max", 2.0))
     desc.num_components = int(getattr(policy, "num_components", 0) or 0)
     desc.layernorm = 1 if norms else 0
-    parts = []
+    tensors = []
     for i, mod in enumerate(linears):
-        parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
+        tensors += [mod.weight, mod.bias]
         if norms:
-            parts += [norms[i].weight.detach().cpu().numpy().ravel(), norms[i].bias.detach().cpu().numpy().ravel()]
+            tensors += [norms[i].weight, norms[i].bias]
     for mod in (policy.value_head, policy.dist_head):
-        parts += [mod.weight.detach().cpu().numpy().ravel(), mod.bias.detach().cpu().numpy().ravel()]
-    blob = np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+        tensors += [mod.weight, mod.bias]
+    return desc, tensors
+
+
+def policy_blob(policy):
+    """Flatten a torch policy into (AzgMlpDesc, float32 host blob) in state_dict order (see policy_tensors)."""
+    desc, tensors = policy_tensors(policy)
+    blob = np.ascontiguousarray(np.concatenate([t.detach().cpu().numpy().ravel() for t in tensors]), dtype=np.float32)
     return desc, blob
 
 
@@ -263,9 +272,32 @@ class Engine:
         if self.mode == MODE_CONTINUOUS:
             self.n_dist = desc.n_dist
 
+    def set_weights_device(self, desc, device_ptr, n_floats):
+        """azg_set_weights_device: the flat float32 blob already lives on the engine's GPU (complete: producer stream synchronised)."""
+        self._check(self._f["set_weights_device"](self._h, C.byref(desc), C.c_void_p(int(device_ptr)), int(n_floats)))
+        if self.mode == MODE_CONTINUOUS:
+            self.n_dist = desc.n_dist
+
     def set_policy(self, policy):
+        """Push a torch policy's weights.  Parameters on the engine's GPU are flattened there (one torch.cat into a device
+        buffer) and re-laid-out by the engine's gather kernel: nothing crosses PCIe; CPU parameters take the host path."""
+        par = next(policy.parameters(), None)
+        if par is not None and par.is_cuda and par.device.index == self.cfg.device_id:
+            import torch
+            desc, tensors = policy_tensors(policy)
+            with torch.no_grad():
+                flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+            torch.cuda.current_stream(par.device).synchronize()
+            self.set_weights_device(desc, flat.data_ptr(), flat.numel())
+            return
         desc, blob = policy_blob(policy)
         self.set_weights(desc, blob)
+
+    def results_resident(self):
+        """azg_results_resident: launch return_results into the engine's device buffers; their addresses as a dict of ints."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self._check(self._f["results_resident"](self._h, *[C.byref(p) for p in ptrs]))
+        return dict(zip(("actions", "counts", "Q", "v_target", "n_children"), (p.value for p in ptrs)))
 
     def set_search_index(self, idx):
         self._check(self._f["set_search_index"](self._h, int(idx)))

@@ -161,27 +161,34 @@ class DeviceReplay:
     of the valid part of the ring; iteration yields minibatches ``(states, actions, counts, Qs, values)`` as device tensors
     gathered on the GPU."""
 
-    def __init__(self, engine, batch_size: int, device=None):
+    def __init__(self, engine, batch_size: int, device=None, wrap=None):
+        """``wrap(ptr, shape, device) -> tensor``: how the ring's device pointer becomes a tensor; default: zero-copy through the
+        CUDA array interface on the engine's GPU."""
         import torch
         self.engine = engine
         self.batch_size = int(batch_size)
-        ptr, cap_rows, row_len = engine.selfplay_rows_device()
-        self.row_len, self.capacity_rows = row_len, cap_rows
-        self.K = (row_len - 1 - engine.s_obs) // 3
         if device is None:
             device = torch.device("cuda", int(engine.cfg.device_id))
         self.device = torch.device(device)
-        if self.device.type == "cuda":
-            self._ring = torch.as_tensor(_DeviceArray(ptr, (cap_rows, row_len)), device=self.device)
-        else:   # the CPU oracle standing in for the engine in tests: its "device" pointer is host memory
-            import ctypes
-            buf = (ctypes.c_float * (cap_rows * row_len)).from_address(ptr)
-            self._ring = torch.from_numpy(np.frombuffer(buf, dtype=np.float32).reshape(cap_rows, row_len))
+        self._wrap = wrap if wrap is not None else (lambda ptr, shape, dev: torch.as_tensor(_DeviceArray(ptr, shape), device=dev))
+        self._ptr = None
+        self._attach()
         self._sampler = _EpochSampler(self.batch_size)
+
+    def _attach(self):
+        """(Re-)wrap the engine's ring: azg_selfplay_begin allocates a new one, the view of the old one must not be used again."""
+        ptr, cap_rows, row_len = self.engine.selfplay_rows_device()
+        if ptr != self._ptr or (cap_rows, row_len) != (self.capacity_rows, self.row_len):
+            self._ptr, self.capacity_rows, self.row_len = ptr, cap_rows, row_len
+            self.K = (row_len - 1 - self.engine.s_obs) // 3
+            self._ring = self._wrap(ptr, (cap_rows, row_len), self.device)
+
+    capacity_rows = row_len = 0
 
     @property
     def ring(self):
         """The whole ring [capacity_rows, row_len] as a zero-copy tensor (slots beyond ``size`` are undefined)."""
+        self._attach()
         return self._ring
 
     @property
@@ -195,7 +202,7 @@ class DeviceReplay:
     def rows(self):
         """Zero-copy view [size, row_len] of the stored rows in slot order (waits for the engine's stream first)."""
         self.engine.sync()
-        return self._ring[:self.size]
+        return self.ring[:self.size]
 
     def split(self, rows):
         so, K = self.engine.s_obs, self.K

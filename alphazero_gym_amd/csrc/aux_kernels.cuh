@@ -96,7 +96,7 @@ struct SelfPlay {
     int max_len, deterministic;
     int final_selection;      // AZG_FS_*
     double agent_eps;         // ContinuousAgent.epsilon
-    const double* ctab;       // c^temperature for c = 0..n_sims (NULL: temperature 1)
+    const double* ctab;       // (c / m)^temperature at [m (m + 1) / 2 + c], 0 <= c <= m <= n_sims, built by the host (NULL: temperature 1)
     unsigned step_idx;
     int* t; int* episode; int* fcnt;
     double* ret; double* fsum;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
             if (a < nc) {
                 const RecL h = rv.rec(a);
                 if (sp.final_selection == AZG_FS_MAX_VALUE) x[a] = h.Q / qmax;
-                else x[a] = sp.ctab ? sp.ctab[h.edge_n] / sp.ctab[cmax] : (double)h.edge_n / (double)cmax;
+                else x[a] = sp.ctab ? sp.ctab[(size_t)cmax * (cmax + 1) / 2 + h.edge_n] : (double)h.edge_n / (double)cmax;
                 sum = sum + x[a];
             }
         }

@@ -113,30 +113,12 @@ static bool use_lockstep(const azg_engine* e) {
 // The search is then run again, with the same search index, as per-layer launches -- which the engine uses from then on.
 extern "C" int azg_search_resident(azg_engine* e);
 static int team_check(azg_engine* e) {
-    if (!e->team_pending && !e->pair_pending) return AZG_OK;
+    if (!e->team_pending) return AZG_OK;
     unsigned flag = 0;
-    if (e->team_pending) {
-        e->team_pending = 0;
-        if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
-        if (flag) e->opt.ls_team = 0;
-    } else {
-        // (the walker + server pair of pair.cuh gives up the same way; the search is rerun by the one-kernel form)
-        e->pair_pending = 0;
-        if (hipMemcpy(&flag, e->d_pair_cnt + (e->pair_cnt_words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(e, AZG_E_DEVICE, "reading the kernel pair's status failed");
-        if (flag) e->opt.pair = 0;
-        if (flag && getenv("AZG_DEBUG")) {
-            unsigned tail[64];
-            if (hipMemcpy(tail, e->d_pair_cnt + (e->pair_cnt_words - 64), sizeof(tail), hipMemcpyDeviceToHost) == hipSuccess) {
-                fprintf(stderr, "azgym pair gave up; walkers started per XCD:");
-                for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", tail[i]);
-                fprintf(stderr, "; servers:");
-                for (int i = 8; i < 16; ++i) fprintf(stderr, " %u", tail[i]);
-                fprintf(stderr, "\n");
-            }
-        }
-    }
+    e->team_pending = 0;
+    if (hipMemcpy(&flag, e->d_team_cnt + (e->team_cnt_bytes / 4 - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(e, AZG_E_DEVICE, "reading the team kernel's status failed");
+    if (flag) e->opt.ls_team = 0;
     if (flag == 0) return AZG_OK;
     e->team_fallbacks += 1;
     e->search_idx = e->team_search_idx;
@@ -159,6 +141,7 @@ void azg_engine_destroy(azg_engine* e) {
     for (void* p : e->dev_allocs) (void)hipFree(p);
     for (void* p : e->dist_allocs) (void)hipFree(p);
     if (e->d_wblob) (void)hipFree(e->d_wblob);
+    if (e->d_wmap) (void)hipFree(e->d_wmap);
     if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
@@ -167,13 +150,6 @@ void azg_engine_destroy(azg_engine* e) {
         if (e->ls_join[p]) (void)hipEventDestroy(e->ls_join[p]);
     }
     if (e->ls_fork) (void)hipEventDestroy(e->ls_fork);
-    if (e->pair_stream) (void)hipStreamSynchronize(e->pair_stream);
-    if (e->d_pair_obs) (void)hipFree(e->d_pair_obs);
-    if (e->d_pair_parts) (void)hipFree(e->d_pair_parts);
-    if (e->d_pair_cnt) (void)hipFree(e->d_pair_cnt);
-    if (e->pair_fork) (void)hipEventDestroy(e->pair_fork);
-    if (e->pair_join) (void)hipEventDestroy(e->pair_join);
-    if (e->pair_stream) (void)hipStreamDestroy(e->pair_stream);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -205,14 +181,12 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
     { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
-    e->opt.pair = env_digit("AZG_PAIR", 0);
     e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0; e->team_fallbacks = 0; e->team_search_idx = 0;
-    e->d_pair_obs = nullptr; e->d_pair_parts = nullptr; e->d_pair_cnt = nullptr; e->pair_cnt_words = 0; e->pair_alloc_pairs = 0; e->pair_alloc_per = 0;
-    e->pair_stream = nullptr; e->pair_fork = nullptr; e->pair_join = nullptr; e->pair_pending = 0; e->kernel_form = -1;
+    e->kernel_form = -1;
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr;
     e->carry_max = 0;
-    e->d_wblob = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
+    e->d_wblob = nullptr; e->d_wmap = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
     e->d_eval = nullptr; e->eval_floats = 0;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
@@ -307,8 +281,20 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
 static int pad64(int n) { return (n + 63) / 64 * 64; }
 static inline int unit_of(int i) { int t = i >> 4, r = (i >> 2) & 3, g = i & 3; return 16 * t + 4 * g + r; }
 
-int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, size_t n_floats) {
-    if (!e || !d || !blob) return AZG_E_INVALID;
+// ---- weights: from the caller's torch-layout blob to the kernels' operand layouts.
+// The re-layout is a pure gather (every element of the engine's weight buffer is one element of the blob or a padding zero), so
+// it is described ONCE per network shape by an index map (WeightMap::src: 1 + blob index, 0 = zero) and then applied either on the
+// host (azg_set_weights: blob in host memory, one H2D copy of the result) or by a gather kernel (azg_set_weights_device: blob in
+// device memory, e.g. the parameters PyTorch just updated or an RCCL broadcast buffer -- no host round trip).  Same map, same
+// numbers, whichever side applies it.
+static bool same_desc(const azg_mlp_desc& a, const azg_mlp_desc& b) {
+    if (a.in_dim != b.in_dim || a.n_hidden != b.n_hidden || a.n_dist != b.n_dist || a.layernorm != b.layernorm) return false;
+    for (int l = 0; l < a.n_hidden; ++l) if (a.hidden[l] != b.hidden[l]) return false;
+    return true;
+}
+
+// validation shared by both entry points; HP_out = common padded hidden width, ncomp_out = mixture components (0: none)
+static int check_desc(azg_engine* e, const azg_mlp_desc* d, size_t n_floats, int* HP_out, int* ncomp_out) {
     if (d->struct_size != (int32_t)sizeof(azg_mlp_desc)) return fail(e, AZG_E_INVALID, "azg_mlp_desc size mismatch");
     if (d->n_hidden < 1 || d->n_hidden > AZG_MAX_HIDDEN_LAYERS) return fail(e, AZG_E_INVALID, "n_hidden out of range");
     if (d->activation < 0 || d->activation > AZG_ACT_HARDSWISH) return fail(e, AZG_E_INVALID, "unknown activation");
@@ -333,123 +319,170 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     const int HP = pad64(hmax);
     if (HP != 64 && HP != 128 && HP != 256 && HP != 512 && HP != 1024)
         return fail(e, AZG_E_UNSUPPORTED, "hidden width (padded to a multiple of 64) must be one of 64,128,256,512,1024");
-    ON_DEVICE(e);
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    // nothing below may leave a half-updated weight set usable: the flag goes up again only on success
-    e->mlp_ready = 0;
-    e->results_valid = 0;
+    *HP_out = HP;
+    *ncomp_out = ncomp;
+    return AZG_OK;
+}
+
+// the index map of a network shape: where every element of the engine's weight buffer comes from
+static void build_weight_map(const azg_mlp_desc* d, int HP, WeightMap& m) {
+    typedef unsigned idx_t;   // 1 + index into the blob; 0: padding
     const int NT = HP / 16, S4 = HP / 16;
-    // unpack the torch-layout blob into zero-padded [HP][Kp] matrices
-    std::vector<std::vector<float>> Wd(d->n_hidden), bd(d->n_hidden), gd(d->n_hidden), ed(d->n_hidden);
-    const float* p = blob;
+    // the blob's tensors as zero-padded [HP][Kp] index matrices (blob order = state_dict order: per layer weight, bias
+    // (, LayerNorm weight, bias), then value head, distribution head)
+    std::vector<std::vector<idx_t>> Wd(d->n_hidden), bd(d->n_hidden), gd(d->n_hidden), ed(d->n_hidden);
+    idx_t p = 1;
     int kt = d->in_dim, kp = 4;
     for (int l = 0; l < d->n_hidden; ++l) {
-        int h = d->hidden[l];
-        Wd[l].assign((size_t)HP * kp, 0.0f);
-        bd[l].assign(HP, 0.0f);
+        const int h = d->hidden[l];
+        Wd[l].assign((size_t)HP * kp, 0);
+        bd[l].assign(HP, 0);
         for (int n = 0; n < h; ++n)
-            for (int kk = 0; kk < kt; ++kk) Wd[l][(size_t)n * kp + kk] = p[(size_t)n * kt + kk];
-        p += (size_t)h * kt;
-        for (int n = 0; n < h; ++n) bd[l][n] = p[n];
+            for (int kk = 0; kk < kt; ++kk) Wd[l][(size_t)n * kp + kk] = p + (idx_t)((size_t)n * kt + kk);
+        p += (idx_t)((size_t)h * kt);
+        for (int n = 0; n < h; ++n) bd[l][n] = p + n;
         p += h;
-        gd[l].assign(HP, 0.0f);
-        ed[l].assign(HP, 0.0f);
+        gd[l].assign(HP, 0);
+        ed[l].assign(HP, 0);
         if (d->layernorm) {
-            for (int n = 0; n < h; ++n) gd[l][n] = p[n];
+            for (int n = 0; n < h; ++n) gd[l][n] = p + n;
             p += h;
-            for (int n = 0; n < h; ++n) ed[l][n] = p[n];
+            for (int n = 0; n < h; ++n) ed[l][n] = p + n;
             p += h;
         }
         kt = h; kp = HP;
     }
-    const int n_out = 1 + d->n_dist;
-    std::vector<float> Wh((size_t)16 * HP, 0.0f), bh(16, 0.0f);
-    for (int kk = 0; kk < kt; ++kk) Wh[kk] = p[kk];
+    std::vector<idx_t> Wh((size_t)16 * HP, 0), bh(16, 0);
+    for (int kk = 0; kk < kt; ++kk) Wh[kk] = p + kk;
     p += kt;
-    bh[0] = *p++;
+    bh[0] = p++;
     for (int o = 0; o < d->n_dist; ++o)
-        for (int kk = 0; kk < kt; ++kk) Wh[(size_t)(1 + o) * HP + kk] = p[(size_t)o * kt + kk];
-    p += (size_t)d->n_dist * kt;
-    for (int o = 0; o < d->n_dist; ++o) bh[1 + o] = p[o];
-    // All re-laid-out tensors go into ONE host staging vector and ONE device buffer (one H2D copy per weight sync; the buffer
-    // is reused while the network shape stays the same, i.e. across every optimiser step of a training run).
-    // MFMA operand layouts (lane l: row/col = l & 15, k-slot g = l >> 4; D register r of tile t = unit 16t + 4g + r)
-    std::vector<float>& st = e->w_stage;
+        for (int kk = 0; kk < kt; ++kk) Wh[(size_t)(1 + o) * HP + kk] = p + (idx_t)((size_t)o * kt + kk);
+    p += (idx_t)((size_t)d->n_dist * kt);
+    for (int o = 0; o < d->n_dist; ++o) bh[1 + o] = p + o;
+    // MFMA operand layouts (lane l: row/col = l & 15, k-slot g = l >> 4; D register r of tile t = unit 16t + 4g + r); every
+    // tensor starts 256-byte aligned in ONE buffer (one H2D copy / one gather per weight sync)
+    std::vector<idx_t>& st = m.src;
     st.clear();
-    auto reserve = [&](size_t n) { size_t off = st.size(); st.resize(off + (n + 63) / 64 * 64, 0.0f); return off; };   // 256-byte aligned
-    const size_t oW0 = reserve((size_t)NT * 64), ob0 = reserve((size_t)NT * 64 * 4);
+    auto reserve = [&](size_t n) { size_t off = st.size(); st.resize(off + (n + 63) / 64 * 64, 0); return off; };
+    m.oW0 = reserve((size_t)NT * 64); m.ob0 = reserve((size_t)NT * 64 * 4);
     for (int t = 0; t < NT; ++t)
         for (int l = 0; l < 64; ++l) {
-            int row = 16 * t + (l & 15), g = l >> 4;
-            st[oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
-            for (int r = 0; r < 4; ++r) st[ob0 + ((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
+            const int row = 16 * t + (l & 15), g = l >> 4;
+            st[m.oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
+            for (int r = 0; r < 4; ++r) st[m.ob0 + ((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
         }
-    const size_t oW0u = reserve((size_t)HP * 4), ob0u = reserve((size_t)HP);
+    m.oW0u = reserve((size_t)HP * 4); m.ob0u = reserve((size_t)HP);
     for (int u = 0; u < HP; ++u) {
-        for (int kk = 0; kk < 4; ++kk) st[oW0u + (size_t)u * 4 + kk] = Wd[0][(size_t)u * 4 + kk];
-        st[ob0u + u] = bd[0][u];
+        for (int kk = 0; kk < 4; ++kk) st[m.oW0u + (size_t)u * 4 + kk] = Wd[0][(size_t)u * 4 + kk];
+        st[m.ob0u + u] = bd[0][u];
     }
-    size_t oWl[MAX_STREAM_LAYERS] = {0}, obl[MAX_STREAM_LAYERS] = {0};
+    for (int l = 0; l < MAX_STREAM_LAYERS; ++l) { m.oWl[l] = m.obl[l] = m.olg[l] = m.olb[l] = 0; }
     for (int l = 1; l < d->n_hidden; ++l) {
         const size_t oW = reserve((size_t)NT * S4 * 64 * 4), ob = reserve((size_t)NT * 64 * 4);
-        oWl[l - 1] = oW; obl[l - 1] = ob;
+        m.oWl[l - 1] = oW; m.obl[l - 1] = ob;
         for (int t = 0; t < NT; ++t)
             for (int l64 = 0; l64 < 64; ++l64) {
-                int row = 16 * t + (l64 & 15), g = l64 >> 4;
+                const int row = 16 * t + (l64 & 15), g = l64 >> 4;
                 for (int s4 = 0; s4 < S4; ++s4)
                     for (int j = 0; j < 4; ++j) {
-                        int i = 4 * (4 * s4 + j) + g;   // canonical position consumed by k-slot g of step 4*s4+j
+                        const int i = 4 * (4 * s4 + j) + g;   // canonical position consumed by k-slot g of step 4*s4+j
                         st[oW + (((size_t)t * S4 + s4) * 64 + l64) * 4 + j] = Wd[l][(size_t)row * HP + unit_of(i)];
                     }
                 for (int r = 0; r < 4; ++r) st[ob + ((size_t)t * 64 + l64) * 4 + r] = bd[l][16 * t + 4 * g + r];
             }
     }
-    const size_t oWh = reserve((size_t)S4 * 64 * 4), obh = reserve(16);
+    m.oWh = reserve((size_t)S4 * 64 * 4); m.obh = reserve(16);
     for (int s4 = 0; s4 < S4; ++s4)
         for (int l64 = 0; l64 < 64; ++l64) {
-            int o = l64 & 15, g = l64 >> 4;
+            const int o = l64 & 15, g = l64 >> 4;
             for (int j = 0; j < 4; ++j) {
-                int i = 4 * (4 * s4 + j) + g;
-                st[oWh + ((size_t)s4 * 64 + l64) * 4 + j] = Wh[(size_t)o * HP + unit_of(i)];
+                const int i = 4 * (4 * s4 + j) + g;
+                st[m.oWh + ((size_t)s4 * 64 + l64) * 4 + j] = Wh[(size_t)o * HP + unit_of(i)];
             }
         }
-    for (int o = 0; o < 16; ++o) st[obh + o] = bh[o];
-    size_t olg[MAX_STREAM_LAYERS] = {0}, olb[MAX_STREAM_LAYERS] = {0};
+    for (int o = 0; o < 16; ++o) st[m.obh + o] = bh[o];
     if (d->layernorm)
         for (int l = 0; l < d->n_hidden; ++l) {
-            olg[l] = reserve((size_t)NT * 64 * 4); olb[l] = reserve((size_t)NT * 64 * 4);
+            m.olg[l] = reserve((size_t)NT * 64 * 4); m.olb[l] = reserve((size_t)NT * 64 * 4);
             for (int t = 0; t < NT; ++t)
                 for (int l64 = 0; l64 < 64; ++l64)
                     for (int r = 0; r < 4; ++r) {
-                        st[olg[l] + ((size_t)t * 64 + l64) * 4 + r] = gd[l][16 * t + 4 * (l64 >> 4) + r];
-                        st[olb[l] + ((size_t)t * 64 + l64) * 4 + r] = ed[l][16 * t + 4 * (l64 >> 4) + r];
+                        st[m.olg[l] + ((size_t)t * 64 + l64) * 4 + r] = gd[l][16 * t + 4 * (l64 >> 4) + r];
+                        st[m.olb[l] + ((size_t)t * 64 + l64) * 4 + r] = ed[l][16 * t + 4 * (l64 >> 4) + r];
                     }
         }
-    if (st.size() != e->w_floats || !e->d_wblob) {
+    m.desc = *d;
+    m.HP = HP;
+    m.valid = true;
+}
+
+__global__ __launch_bounds__(256) void weight_gather_kernel(const unsigned* __restrict__ src, const float* __restrict__ blob,
+                                                            float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const unsigned s = src[i]; out[i] = s ? blob[s - 1] : 0.0f; }
+}
+
+// Common body of azg_set_weights / azg_set_weights_device: `blob` is a host pointer (on_device false) or a device pointer whose
+// contents are complete (its producer's stream synchronised or otherwise ordered before this call).
+static int set_weights_impl(azg_engine* e, const azg_mlp_desc* d, const float* blob, size_t n_floats, bool on_device) {
+    if (!e || !d || !blob) return AZG_E_INVALID;
+    int HP = 0, ncomp = 0;
+    { int rc = check_desc(e, d, n_floats, &HP, &ncomp); if (rc) return rc; }
+    ON_DEVICE(e);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    { int trc = team_check(e); if (trc) return trc; }   // an abandoned team search is redone with the weights it was started with
+    // nothing below may leave a half-updated weight set usable: the flag goes up again only on success
+    e->mlp_ready = 0;
+    e->results_valid = 0;
+    WeightMap& m = e->wmap;
+    if (!m.valid || m.HP != HP || !same_desc(m.desc, *d)) {
+        m.valid = false;
+        build_weight_map(d, HP, m);
+        if (e->d_wmap) { (void)hipFree(e->d_wmap); e->d_wmap = nullptr; }   // (uploaded when the device path first needs it)
+    }
+    const size_t n_out_f = m.src.size();
+    if (n_out_f != e->w_floats || !e->d_wblob) {
         if (e->d_wblob) (void)hipFree(e->d_wblob);
         e->d_wblob = nullptr; e->w_floats = 0;
         void* q = nullptr;
-        HIPCHK(e, hipMalloc(&q, st.size() * sizeof(float)));
-        e->d_wblob = (float*)q; e->w_floats = st.size();
+        HIPCHK(e, hipMalloc(&q, n_out_f * sizeof(float)));
+        e->d_wblob = (float*)q; e->w_floats = n_out_f;
     }
-    HIPCHK(e, hipMemcpy(e->d_wblob, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (on_device) {
+        if (!e->d_wmap) {
+            void* q = nullptr;
+            HIPCHK(e, hipMalloc(&q, n_out_f * sizeof(unsigned)));
+            e->d_wmap = (unsigned*)q;
+            HIPCHK(e, hipMemcpy(e->d_wmap, m.src.data(), n_out_f * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(weight_gather_kernel, dim3((unsigned)((n_out_f + 255) / 256)), dim3(256), 0, e->stream, e->d_wmap, blob, e->d_wblob, n_out_f);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));   // the caller may overwrite its blob as soon as this returns
+    } else {
+        std::vector<float>& st = e->w_stage;
+        st.resize(n_out_f);
+        const unsigned* src = m.src.data();
+        for (size_t i = 0; i < n_out_f; ++i) st[i] = src[i] ? blob[src[i] - 1] : 0.0f;
+        HIPCHK(e, hipMemcpy(e->d_wblob, st.data(), n_out_f * sizeof(float), hipMemcpyHostToDevice));
+    }
     const float* wb = e->d_wblob;
-    e->P.W0u = (const f32x4*)(wb + oW0u);
-    e->P.b0u = (const f32x4*)(wb + ob0u);
-    e->P.W0 = wb + oW0;
-    e->P.b0 = (const f32x4*)(wb + ob0);
+    e->P.W0u = (const f32x4*)(wb + m.oW0u);
+    e->P.b0u = (const f32x4*)(wb + m.ob0u);
+    e->P.W0 = wb + m.oW0;
+    e->P.b0 = (const f32x4*)(wb + m.ob0);
     for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {
         const bool on = l + 1 < d->n_hidden;
-        e->P.Wl[l] = on ? (const f32x4*)(wb + oWl[l]) : nullptr;
-        e->P.bl[l] = on ? (const f32x4*)(wb + obl[l]) : nullptr;
+        e->P.Wl[l] = on ? (const f32x4*)(wb + m.oWl[l]) : nullptr;
+        e->P.bl[l] = on ? (const f32x4*)(wb + m.obl[l]) : nullptr;
     }
-    e->P.Whead = (const f32x4*)(wb + oWh);
-    e->P.bhead = wb + obh;
+    e->P.Whead = (const f32x4*)(wb + m.oWh);
+    e->P.bhead = wb + m.obh;
     e->P.layernorm = d->layernorm ? 1 : 0;
     for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {
         e->P.Htrue[l] = l < d->n_hidden ? d->hidden[l] : 0;
-        e->P.lng[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + olg[l]) : nullptr;
-        e->P.lnb[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + olb[l]) : nullptr;
+        e->P.lng[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + m.olg[l]) : nullptr;
+        e->P.lnb[l] = (d->layernorm && l < d->n_hidden) ? (const f32x4*)(wb + m.olb[l]) : nullptr;
     }
     if (e->cfg.mode == AZG_MODE_CONTINUOUS && (d->n_dist != e->dist_nd || ncomp != e->dist_ncomp)) {
         // the per-node mixture cache and the root-distribution staging buffer are sized by the head: rebuilt only when it changes
@@ -464,6 +497,7 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
         e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
         e->dist_nd = d->n_dist; e->dist_ncomp = ncomp;
     }
+    const int n_out = 1 + d->n_dist;
     e->HP = HP; e->n_hidden = d->n_hidden; e->n_out = n_out; e->act = d->activation;
     e->P.n_hidden = d->n_hidden; e->P.n_out = n_out; e->P.act = d->activation; e->P.ls_min = d->log_std_min; e->P.ls_max = d->log_std_max;
     // hidden->hidden layers that fit the register file stay there for the whole search
@@ -475,6 +509,14 @@ int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     if (e->opt.force_stream_weights) e->nreg = 0;
     e->mlp_ready = 1;
     return AZG_OK;
+}
+
+int azg_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, size_t n_floats) {
+    return set_weights_impl(e, d, blob, n_floats, false);
+}
+
+int azg_set_weights_device(azg_engine* e, const azg_mlp_desc* d, const float* device_blob, size_t n_floats) {
+    return set_weights_impl(e, d, device_blob, n_floats, true);
 }
 
 int azg_set_search_index(azg_engine* e, uint32_t idx) { if (!e) return AZG_E_INVALID; e->search_idx = idx; return AZG_OK; }
@@ -496,8 +538,13 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
             if (carry[i] < 0 || carry[i] > (1 << 30)) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
             if (carry[i] > cmax) cmax = carry[i];
         }
-    e->carry_max = cmax;
     ON_DEVICE(e);
+    if (e->team_pending) {   // an abandoned team search is redone on the roots it was started with
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int trc = team_check(e);
+        if (trc) return trc;
+    }
+    e->carry_max = cmax;
     HIPCHK(e, hipMemcpyAsync(e->d_roots, roots, sizeof(double) * (size_t)B * S, hipMemcpyHostToDevice, e->stream));
     if (carry) HIPCHK(e, hipMemcpyAsync(e->d_carry, carry, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, e->stream));
     else HIPCHK(e, hipMemsetAsync(e->d_carry, 0, sizeof(int) * (size_t)B, e->stream));
@@ -517,14 +564,8 @@ int azg_search_resident(azg_engine* e) {
     hipError_t rc;
     const bool cartpole = e->cfg.env_id == AZG_ENV_CARTPOLE;
     if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : azg_ls_dispatch_pendulum(e);
-    else {
-        rc = hipErrorNotReady;
-        if (e->opt.pair) rc = cartpole ? azg_pair_dispatch_cartpole(e) : azg_pair_dispatch_pendulum(e);
-        if (rc == hipErrorNotReady) {
-            if (cartpole) rc = azg_dispatch_cartpole(e);
-            else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
-        }
-    }
+    else if (cartpole) rc = azg_dispatch_cartpole(e);
+    else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;
@@ -553,15 +594,19 @@ int azg_last_search_ms(azg_engine* e, float* ms) {
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     ON_DEVICE(e);
     HIPCHK(e, hipEventSynchronize(e->ev1));
+    if (e->team_pending) {   // (the time of the launches that redid an abandoned team search, not of the abandoned launch)
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int trc = team_check(e);
+        if (trc) return trc;
+    }
     HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
     return AZG_OK;
 }
 
-static int gather_results(azg_engine* e) {
+static int launch_results(azg_engine* e) {
     if (!e->searched) return fail(e, AZG_E_STATE, "no search has run");
     if (e->results_valid) return AZG_OK;
-    ON_DEVICE(e);
-    if (e->team_pending || e->pair_pending) {
+    if (e->team_pending) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         int trc = team_check(e);
         if (trc) return trc;
@@ -570,8 +615,15 @@ static int gather_results(azg_engine* e) {
     hipLaunchKernelGGL(results_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
                        e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
     HIPCHK(e, hipGetLastError());
+    e->results_valid = 1;   // (in stream order: whatever reads the buffers is ordered after this launch)
+    return AZG_OK;
+}
+
+static int gather_results(azg_engine* e) {
+    ON_DEVICE(e);
+    int rc = launch_results(e);
+    if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    e->results_valid = 1;
     return AZG_OK;
 }
 
@@ -587,6 +639,20 @@ int azg_results(azg_engine* e, float* actions, int32_t* counts, double* Q, doubl
     D2H(Q, e->d_Q, B * K * 8);
     D2H(v_target, e->d_vt, B * 8);
     D2H(n_children, e->d_nch, B * 4);
+    return AZG_OK;
+}
+
+int azg_results_resident(azg_engine* e, const float** actions, const int32_t** counts, const double** Q, const double** v_target,
+                         const int32_t** n_children) {
+    if (!e) return AZG_E_INVALID;
+    ON_DEVICE(e);
+    int rc = launch_results(e);
+    if (rc) return rc;
+    if (actions) *actions = e->d_actions;
+    if (counts) *counts = e->d_counts;
+    if (Q) *Q = e->d_Q;
+    if (v_target) *v_target = e->d_vt;
+    if (n_children) *n_children = e->d_nch;
     return AZG_OK;
 }
 
@@ -685,7 +751,7 @@ int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1;
 // diagnostic: the form the last search ran in (engine_host.h: kernel_form)
 int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
-// head, waves, tree groups -- see search_kernel.cuh / team.cuh / pair.cuh); returns the length written
+// head, waves, tree groups -- see search_kernel.cuh / team.cuh); returns the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
     const int env = e->cfg.env_id == AZG_ENV_CARTPOLE ? 0 : 2;   // (both Pendulum versions run the ENV = 2 instantiation)
@@ -695,7 +761,6 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
         case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2: w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d>", env, e->HP, gmm, e->tree_lds); break;
-        case 3: w = snprintf(buf, n, "pair_walker_kernel<%d, %d, %d, %s> + pair_server_kernel<%d, %d, %s>", env, e->HP, e->tree_lds, gmm, e->HP, e->nreg, gmm); break;
         default: w = snprintf(buf, n, "(no search yet)");
     }
     return w;
@@ -750,9 +815,13 @@ int azg_selfplay_begin_ex(azg_engine* e, const azg_selfplay_config* c) {
         return AZG_E_DEVICE;
     e->d_sp_ctab = nullptr;
     if (discrete && c->temperature != 1.0) {
-        // c^temperature for every count a root edge can reach (python float pow = libm pow, like check_pw's table)
-        std::vector<double> tab((size_t)e->cfg.n_sims + 1);
-        for (size_t i = 0; i < tab.size(); ++i) tab[i] = std::pow((double)i, c->temperature);
+        // stable_normalizer (helpers.py:10-27) raises x / max(x) to the temperature: (c / m)^t for every pair of a root edge count c
+        // and the root's largest count m that can occur, python float pow = libm pow on the host (like check_pw's table)
+        const size_t ns = (size_t)e->cfg.n_sims;
+        if (ns > 2048) return fail(e, AZG_E_UNSUPPORTED, "temperature != 1 on the device supports n_sims <= 2048");
+        std::vector<double> tab((ns + 1) * (ns + 2) / 2, 0.0);
+        for (size_t m = 1; m <= ns; ++m)
+            for (size_t k = 0; k <= m; ++k) tab[m * (m + 1) / 2 + k] = std::pow((double)k / (double)m, c->temperature);
         if (dalloc(e, &e->d_sp_ctab, tab.size(), e->sp_allocs)) return AZG_E_DEVICE;
         HIPCHK(e, hipMemcpy(e->d_sp_ctab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     }
@@ -788,7 +857,7 @@ int azg_selfplay_step(azg_engine* e) {
     int rc = azg_search_resident(e);
     if (rc) return rc;
     ON_DEVICE(e);
-    if (e->team_pending || e->pair_pending) {   // (wide networks: the persistent team kernel may have given up -- see team_check)
+    if (e->team_pending) {   // (wide networks: the persistent team kernel may have given up -- see team_check)
         HIPCHK(e, hipStreamSynchronize(e->stream));
         rc = team_check(e);
         if (rc) return rc;

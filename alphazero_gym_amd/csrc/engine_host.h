@@ -24,12 +24,18 @@ struct EngineOptions {
                                // (made inside the first hidden layer's operand staging it cost +1 %: removed)
     int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
     long team_spin_limit;      // AZG_TEAM_SPIN_LIMIT=n: polls a team hand-off may wait before the launch gives up (tests: 0)
-    int pair;                  // AZG_PAIR=1: the walker + server kernel pair (pair.cuh) when a batch has more 16-tree groups than the
-                               // device has CUs; 2: whenever the network and the trees allow it (tests).  Default 0: measured at
-                               // 8192 trees x 2x256, 3.15 ms per search against 2.67 ms for the 8-wave one-kernel form
 };
 #define LS_MAX_PIPES 8
 #define AZG_MAX_DEVICES 64    // per-device caches of kernel attributes (host side)
+
+// Where every element of the engine's weight buffer comes from, for one network shape (azg_engine.hip: build_weight_map)
+struct WeightMap {
+    bool valid = false;
+    azg_mlp_desc desc;
+    int HP = 0;
+    std::vector<unsigned> src;   // per output float: 1 + index into the caller's blob, 0 = padding zero
+    size_t oW0, ob0, oW0u, ob0u, oWl[MAX_STREAM_LAYERS], obl[MAX_STREAM_LAYERS], oWh, obh, olg[MAX_STREAM_LAYERS], olb[MAX_STREAM_LAYERS];
+};
 
 struct azg_engine {
     azg_config cfg;
@@ -48,6 +54,8 @@ struct azg_engine {
     float* d_wblob;          // every re-laid-out weight tensor of the current network in one buffer (reused while the shape stays)
     size_t w_floats;
     std::vector<float> w_stage;      // host staging of that buffer
+    WeightMap wmap;                  // the re-layout as an index map, rebuilt when the network shape changes
+    unsigned* d_wmap;                // its device copy (azg_set_weights_device)
     std::vector<void*> dist_allocs;  // continuous mode: per-node mixture cache + root distribution staging, sized by the head
     int dist_nd, dist_ncomp;
     // results staging
@@ -69,11 +77,7 @@ struct azg_engine {
     int team_pending;        // a team kernel has been launched since its abort word was last read
     int team_fallbacks;      // searches it gave up on (redone by the per-layer launches)
     uint32_t team_search_idx;
-    // walker + server kernel pair (pair.cuh): hand-off buffers, the server's stream, fork / join events
-    float* d_pair_obs; f32x4* d_pair_parts; unsigned* d_pair_cnt; size_t pair_cnt_words; int pair_alloc_pairs, pair_alloc_per;
-    hipStream_t pair_stream; hipEvent_t pair_fork, pair_join;
-    int pair_pending;        // a pair has been launched since its abort word was last read
-    int kernel_form;         // what the last search ran as: 0 search_kernel, 1 lock-step launches, 2 team kernel, 3 walker + server pair
+    int kernel_form;         // what the last search ran as: 0 search_kernel, 1 lock-step launches, 2 team kernel
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;
@@ -91,9 +95,6 @@ hipError_t azg_ls_dispatch_cartpole(azg_engine* e);      // lock-step path (lock
 hipError_t azg_ls_dispatch_pendulum(azg_engine* e);
 // the same search as ONE persistent launch (team.cuh); hipErrorNotReady: its workgroups cannot all be resident, use the launches
 hipError_t azg_team_dispatch_cartpole(azg_engine* e);
-// walker + server kernel pair (pair.cuh) for batches with more 16-tree groups than CUs; hipErrorNotReady: not applicable here
-hipError_t azg_pair_dispatch_cartpole(azg_engine* e);
-hipError_t azg_pair_dispatch_pendulum(azg_engine* e);
 hipError_t azg_team_dispatch_pendulum(azg_engine* e);
 // batched network inference of n observations (device pointers) on e->stream (mlp_eval.cuh)
 hipError_t azg_dispatch_mlp_eval(azg_engine* e, const float* obs, int n, float* value, float* dist, float* raw);

@@ -132,7 +132,7 @@ __device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4
 // enough for value + Normal / 2-action heads).  Activations cross waves through the act buffers ([group][HP/16 tiles][64 lanes]
 // float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in registers until the next layer
 // publishes it, and the last layer's output feeds the head MFMAs directly.
-// (WR: WRegs<HP, NREG, NW>, or a look-alike that keeps some of the small operands elsewhere -- pair.cuh's server)
+// (WR: WRegs<HP, NREG, NW>, or a look-alike that keeps some of the small operands elsewhere -- tools/probes/pair's server)
 template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, const float* obsT, f32x4* actA, f32x4* actB,
                                             f32x4* parts, float* s_ln, int wave, int lane

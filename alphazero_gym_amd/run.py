@@ -237,6 +237,7 @@ class DeviceSelfPlay:
             rows = replay.rows().clone()
             self.engine.selfplay_clear()
             return rows
+        assert n_steps <= self.capacity, "the ring keeps its newest capacity_steps steps: older ones would already be overwritten"
         before = self.engine.selfplay_ring()
         self.play(n_steps)
         size, insert, _ = self.engine.selfplay_ring()

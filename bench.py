@@ -6,12 +6,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N = 1  (config C): a "step" is one whole search (4096 trees x 200 simulations = ONE launch of the fused search kernel) over
-       synthetic fixed-seed root states already resident in HBM.  The JSON line also carries `extra`: configs B and E timed
+       synthetic fixed-seed root states already resident in HBM, plus return_results for every tree into device buffers
+       (azg_results_resident: one small launch, no copy).  The JSON line also carries `extra`: configs B and E timed
        the same way, the PCIe-inclusive rate of config C, and the CPU baselines.
+       `--config-d` runs the N > 1 loop (below) with one rank: the collectives then go through RCCL with world size 1.
 N > 1  (config D): one process per GPU (spawned here when the script was not started by torch.distributed.run), 4096 self-play
        games per GPU keyed by global game id.  A step is one device-resident self-play step (search + final action + env step +
        replay row) PLUS the all-gather of the step's replay rows over RCCL (HBM to HBM, overlapped with the next step's search)
-       and a weight broadcast + engine re-sync every --bcast-every steps: the loop shape of run_continuous.py:111-155 scaled out.
+       and a weight broadcast + engine re-sync (device to device: azg_set_weights_device) every --bcast-every steps: the loop
+       shape of run_continuous.py:111-155 scaled out.
        `extra.search_only` is the same loop without the collectives.
 Rank 0 prints ONE JSON line.
 """
@@ -44,22 +47,24 @@ def mlp_flops(in_dim, hidden, n_out):
 FLOP_PER_SIM = mlp_flops(3, HIDDEN, 3)   # 134 144
 
 
-def profiled_traffic():
+def profiled_traffic(tag=""):
     """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_summary.csv; FETCH_SIZE and WRITE_SIZE are collected in separate passes, in KiB; gfx950 reports half
-    of the bytes of wide coalesced reads, so the read side is doubled as the microarch guide prescribes -- an upper bound
-    for this kernel's narrow reads).  None when no profile is committed."""
+    (profiles/*_pmc_summary.csv, or profiles/*_config<tag>_pmc_summary.csv; FETCH_SIZE and WRITE_SIZE are collected in separate
+    passes, in KiB; gfx950 reports half of the bytes of wide coalesced reads, so the read side is doubled as the microarch guide
+    prescribes -- an upper bound for this kernel's narrow reads).  (bytes, file name) or (None, None) when no profile is committed."""
     import csv
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")) if "config" not in os.path.basename(f))
-    if not files:
-        return None
-    vals = {}
-    for r in csv.DictReader(open(files[-1])):
-        vals[r["counter"]] = float(r["mean_per_launch"])
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    if tag:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_config{tag}_pmc_summary.csv")))
+    else:
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")) if "config" not in os.path.basename(f))
+    for f in reversed(files):
+        vals = {}
+        for r in csv.DictReader(open(f)):
+            vals[r["counter"]] = float(r["mean_per_launch"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def physical_cores():
@@ -167,7 +172,24 @@ def kernel_name(eng):
     return buf.value.decode() if n > 0 else "?"
 
 
-def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, kernels, flops_per_sim, note, device_id):
+PEAK_HBM_GBS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def tree_walk_bytes(dump, n_actions, n_sims):
+    """SURVEY 8d's declared minimal SoA traffic of the tree walk, from the searched trees themselves:
+    bytes = 16 L + 12 C (+ 4 C priors, discrete) + 56 L + 92 E + 40 per simulation, with L = levels descended (every traversal of
+    an edge increments its count: sum of edge counts), C = children scanned (discrete: all n_actions per level), E = expansions
+    (new nodes: records / n_actions).  Returns (bytes per simulation, L, C, E) averaged over all trees (discrete mode)."""
+    B = dump["n_records"].shape[0]
+    sims = float(B * n_sims)
+    L = float(dump["edge_n"].sum()) / sims
+    C = n_actions * L
+    E = float((dump["n_records"] - 1).sum()) / n_actions / sims
+    return 16 * L + 16 * C + 56 * L + 92 * E + 40, L, C, E
+
+
+def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, flops_per_sim, note, device_id, hbm_tag=None):
+    import ctypes as C
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
     eng = _native.HipEngine(n_trees=trees, n_sims=n_sims, device_id=device_id, **kw)
@@ -177,12 +199,26 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, kernels, 
     res = eng.results()
     assert (res["counts"].sum(1) == n_sims).all()
     ran = kernel_name(eng)
-    assert ran == kernels[0], f"{name}: expected {kernels[0]}, the engine ran {ran}"
-    eng.close()
+    fallbacks = _native.lib().azg_debug_team_fallbacks(C.c_void_p(eng._h.value))
     ach = trees * n_sims * flops_per_sim / (med * 1e-3) / 1e12
-    return {"config": name, "ms_per_search": med, "ms_mean": mean, "sims_per_s": trees * n_sims / (med * 1e-3), "trees": trees, "n_sims": n_sims,
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS}, "kernels": kernels,
-            "note": note}
+    out = {"config": name, "ms_per_search": med, "ms_mean": mean, "sims_per_s": trees * n_sims / (med * 1e-3), "trees": trees, "n_sims": n_sims,
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS},
+           "kernels": [ran], "note": note}
+    if ran != expect:
+        out["fallback"] = f"expected {expect}; the engine ran {ran} (team-kernel fallbacks: {fallbacks})"
+    if hbm_tag:
+        # the tree-walk-bound config also gets SURVEY 8d's HBM-side figure: declared minimal bytes of the walk / time / HBM peak
+        per_sim, L, Cn, E = tree_walk_bytes(eng.dump_tree(), kw.get("num_actions", 2), n_sims)
+        gbs = trees * n_sims * per_sim / (med * 1e-3) / 1e9
+        traffic, src = profiled_traffic(hbm_tag)
+        out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                               "traffic": traffic, "bytes_per_sim": per_sim, "levels_per_sim": L, "children_per_sim": Cn,
+                               "expansions_per_sim": E,
+                               "note": "algorithmic bytes = 16L + 12C + 4C + 56L + 92E + 40 per simulation (SURVEY 8d) with L, C, E counted "
+                                       "from the searched trees; traffic = HBM bytes per launch from the committed PMC passes"
+                                       + (f" ({src})" if src else " (none committed yet)")}
+    eng.close()
+    return out
 
 
 def spawn(args):
@@ -192,8 +228,9 @@ def spawn(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--backend", args.backend]
-    if args.same_device:
-        cmd.append("--same-device")
+    for flag, on in (("--same-device", args.same_device), ("--config-d", args.config_d), ("--verify-gather", args.verify_gather)):
+        if on:
+            cmd.append(flag)
     sys.exit(subprocess.call(cmd))
 
 
@@ -206,11 +243,14 @@ def main():
     ap.add_argument("--bcast-every", type=int, default=10, help="N > 1: weight broadcast + engine re-sync every this many steps")
     ap.add_argument("--backend", default="nccl", help="N > 1: nccl (= RCCL) or gloo (functional test of the loop on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="N > 1: every rank on GPU 0 (functional test on a 1-GPU box, with gloo)")
+    ap.add_argument("--config-d", action="store_true", help="run the N > 1 loop (self-play step + all-gather + weight broadcast) also with one rank: "
+                                                            "RCCL with world size 1 on the engine-owned ring")
+    ap.add_argument("--verify-gather", action="store_true", help="N > 1 loop: check every gathered block against the rows the previous step wrote (slow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the config B / E lines")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.config_d):
         spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,15 +284,18 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
-    if world == 1:
+    config_d = world > 1 or args.config_d
+    if not config_d:
         # ---------------- config C: K whole searches, roots resident in HBM
         for _ in range(args.warmup):
             eng.search_resident()
+            eng.results_resident()
         eng.sync()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.search_resident()
+            eng.search_resident()      # the whole search: one launch
+            eng.results_resident()     # return_results of every tree into device buffers: one small launch, no copy
         eng.sync()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -276,25 +319,51 @@ def main():
         RL = ring.shape[-1]
         on_host = args.backend != "nccl"
         gathered = torch.empty((world * B, RL), dtype=torch.float32, device="cpu" if on_host else ring.device)
-        flat = torch.from_numpy(blob.copy()).to(ring.device)
+        flat = torch.from_numpy(blob.copy())
+
+        d_flat = None if on_host else torch.from_numpy(blob.copy()).to(ring.device)
+        verify = {"checked": 0}
+
+        def gather(slot, expect=None):
+            rows = ring[slot]
+            dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
+            torch.cuda.current_stream().synchronize()         # the slot is free again before the step after next is launched
+            if expect is not None:
+                mine = gathered[rank * B:(rank + 1) * B]
+                assert torch.equal(mine.cpu(), expect), "the gathered block is not the block the previous step wrote"
+                verify["checked"] += 1
 
         def run(steps, collectives):
-            """`steps` self-play steps; with collectives, step s-1's rows are all-gathered while step s searches."""
+            """`steps` self-play steps; with collectives, the previous step's rows are all-gathered while this step searches.
+            The ring slot of a step comes from the engine's own account (azg_selfplay_ring: steps played since begin), not from
+            the loop index: the two-slot FIFO ring keeps turning across calls of this function."""
+            prev_slot, expect = None, None
             for s in range(steps):
-                eng.sync()                                        # step s-1 finished (it ran while the host did the last gather)
+                eng.sync()                                        # the previous step finished (it ran while the host did the last gather)
+                if args.verify_gather and prev_slot is not None:
+                    # which slot did the previous step really write?  Compare the ring with its state before that step.
+                    now = ring.clone().cpu()
+                    changed = [i for i in range(2) if not torch.equal(now[i], verify["before"][i])]
+                    assert changed == [prev_slot], (changed, prev_slot)
+                    expect = now[prev_slot]
                 if collectives and s > 0 and s % args.bcast_every == 0:
-                    dist.broadcast(flat, src=0)                   # updated weights from the trainer rank ...
-                    eng.set_weights(desc, flat.cpu().numpy())     # ... into every rank's engine
-                eng.selfplay_step()                               # launches only: step s now runs on the engine's stream
-                if collectives and s > 0:
-                    rows = ring[(s - 1) % 2]
-                    dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
-                    torch.cuda.current_stream().synchronize()     # slot (s-1)%2 is free again before step s+1 is launched
+                    if on_host:                                   # functional run over gloo: staged through the host
+                        dist.broadcast(flat, src=0)
+                        eng.set_weights(desc, flat.numpy())
+                    else:                                         # RCCL broadcast into HBM, re-layout by the engine's gather kernel
+                        dist.broadcast(d_flat, src=0)
+                        torch.cuda.current_stream().synchronize()
+                        eng.set_weights_device(desc, d_flat.data_ptr(), d_flat.numel())
+                if args.verify_gather:
+                    verify["before"] = ring.clone().cpu()
+                total = eng.selfplay_ring()[2]                    # steps played so far = the step about to be launched
+                eng.selfplay_step()                               # launches only: this step now runs on the engine's stream
+                if collectives and prev_slot is not None:
+                    gather(prev_slot, expect)
+                prev_slot = total % 2                             # capacity 2, FIFO: step k lives in slot k % 2
             eng.sync()
-            if collectives and steps > 0:
-                rows = ring[(steps - 1) % 2]
-                dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
-                torch.cuda.current_stream().synchronize()
+            if collectives and prev_slot is not None:
+                gather(prev_slot, ring[prev_slot].clone().cpu() if args.verify_gather else None)
 
         run(args.warmup, True)
         barrier()
@@ -320,7 +389,7 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if args.backend != "nccl" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if world > 1:
+        if config_d:
             t = torch.tensor([plain], device="cpu" if args.backend != "nccl" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             plain = float(t.item())
@@ -329,19 +398,23 @@ def main():
     if rank == 0:
         sims = world * B * N_SIMS * args.steps
         achieved = B * N_SIMS * FLOP_PER_SIM / (kmean * 1e-3) / 1e12
-        if world > 1:
+        if config_d:
             extra["search_only"] = {"sims_per_s": sims / plain, "ms_per_step": plain / args.steps * 1e3,
                                     "note": "the same self-play loop without the all-gather and the weight broadcast"}
+            extra["collectives"] = {"backend": args.backend, "world_size": world, "gathers_verified": verify["checked"],
+                                    "weight_sync": "host (gloo functional run)" if on_host else "device to device: RCCL broadcast into HBM + azg_set_weights_device"}
         elif not args.no_extra:
             extra["configs"] = [
                 extra_config("C at 8192 trees per GPU (the batch shape of real self-play runs: two 16-tree groups per CU)", PENDULUM, 8192, 200, 3, HIDDEN, 2, "elu",
-                             ["search_kernel<2, 256, 1, 1, false, 8, 2>"], FLOP_PER_SIM,
+                             "search_kernel<2, 256, 1, 1, false, 8, 2>", FLOP_PER_SIM,
                              "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
-                             ["search_kernel<0, 128, 1, 1, false, 4, 1>"], 0.26 * mlp_flops(4, [128, 128], 3),
-                             "tree-walk bound (8-9 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction; selections are taken at backup time and stored with the nodes, the descent follows them", dev),
+                             "search_kernel<0, 128, 1, 1, false, 4, 1>", 0.26 * mlp_flops(4, [128, 128], 3),
+                             "tree-walk bound (8-9 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction, "
+                             "the HBM-side figure of SURVEY 8d is in roofline_hbm; selections are taken at backup time and stored with the nodes, "
+                             "the descent follows them", dev, hbm_tag="B"),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
-                             ["ls_team_kernel<2, 1024, false, 1>"],
+                             "ls_team_kernel<2, 1024, false, 1>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
                              "layer for the team's 32 trees each), hand-offs through global memory", dev),
             ]
@@ -352,16 +425,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": profiled_traffic() if B == N_TREES else None,
+                         "traffic": profiled_traffic()[0] if (B == N_TREES and not config_d) else None,
                          "kernel": kname + " (template arguments: ENV 2 = Pendulum, HP = padded hidden width, NREG = hidden->hidden layers held in "
                                    "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup, 16-tree groups per workgroup)",
                          "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
-                                 "the committed rocprofv3 PMC passes (profiles/)"},
+                                 "the committed rocprofv3 PMC passes (" + str(profiled_traffic()[1]) + "), not measured in this run; `value` is wall "
+                                 "time over K steps of search + return_results (results_kernel) with everything resident in HBM, the PCIe-inclusive "
+                                 "rate is extra.pcie_inclusive"},
             "extra": extra,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not config_d and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -93,6 +93,11 @@ const char* azg_last_error(const azg_engine* e); /* e may be NULL: last create e
 
 /* model=self.nn (agents.py:82): copies and re-lays-out the weights; call again after every optimiser step */
 int azg_set_weights(azg_engine* e, const azg_mlp_desc* desc, const float* blob, size_t n_floats);
+/* The same with the blob in DEVICE memory on the engine's GPU (the parameters PyTorch-ROCm just updated, flattened in state_dict
+ * order, or the buffer an RCCL broadcast delivered: run_continuous.py:144-155's train step scaled out).  The re-layout runs as a
+ * gather kernel on the engine's stream: no device -> host -> device hop.  The blob's contents must be complete when this is
+ * called (producer stream synchronised); it may be reused as soon as the call returns.  Same blob, same network as azg_set_weights. */
+int azg_set_weights_device(azg_engine* e, const azg_mlp_desc* desc, const float* device_blob, size_t n_floats);
 
 /* index mixed into the RNG counter; auto-incremented by azg_search */
 int azg_set_search_index(azg_engine* e, uint32_t idx);
@@ -107,6 +112,12 @@ int azg_search(azg_engine* e, const double* root_env_state, const int32_t* root_
  *   actions [B][Kmax] float32 (discrete: the action index as float), counts [B][Kmax] int32,
  *   Q [B][Kmax] float64, v_target [B] float64, n_children [B] int32.  Any pointer may be NULL. */
 int azg_results(azg_engine* e, float* actions, int32_t* counts, double* Q, double* v_target, int32_t* n_children);
+/* The same for consumers on the engine's GPU: return_results of the last search is computed into the engine's own device buffers
+ * (asynchronous: a launch on the engine's stream, no copy, no wait) and their addresses are handed out -- same shapes and dtypes
+ * as azg_results; valid until the engine is destroyed, contents until the next search's results.  Any pointer may be NULL.
+ * Order consumers after the engine's stream (azg_sync) before reading. */
+int azg_results_resident(azg_engine* e, const float** actions, const int32_t** counts, const double** Q, const double** v_target,
+                         const int32_t** n_children);
 
 /* What MCTSDiscrete.forward (mcts.py:495-526) inspects: per root child the child node's visit count
  * (-1: edge has no child node) and its environment state.  child_n [B][Kmax], child_state [B][Kmax][S_env]. */

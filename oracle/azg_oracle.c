@@ -93,6 +93,7 @@ struct azg_engine {
     int sp_insert, sp_fs, sp_ring;
     long long sp_total;
     double sp_temperature, sp_agent_eps;
+    float* res_actions; int32_t* res_counts; double* res_Q; double* res_vt; int32_t* res_nch;   /* azo_results_resident */
     uint32_t sp_step_idx;
     int32_t* sp_t; int32_t* sp_episode; int32_t* sp_fcnt; double* sp_ret; double* sp_fsum; float* sp_rows;
     char err[256];
@@ -335,6 +336,7 @@ void azo_engine_destroy(azg_engine* e) {
     for (int l = 0; l < AZG_MAX_HIDDEN_LAYERS; ++l) { free(e->mlp.W[l]); free(e->mlp.Wp[l]); free(e->mlp.b[l]); free(e->mlp.lng[l]); free(e->mlp.lnb[l]); }
     free(e->mlp.Wh); free(e->mlp.bh); free(e->pw_need); free(e->roots); free(e->carry);
     free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
+    free(e->res_actions); free(e->res_counts); free(e->res_Q); free(e->res_vt); free(e->res_nch);
     free(e);
 }
 
@@ -452,6 +454,9 @@ int azo_set_weights(azg_engine* e, const azg_mlp_desc* d, const float* blob, siz
     m->ready = 1;
     return AZG_OK;
 }
+
+/* (the oracle's "device" is the host: the test-suite binds both engines through one table of entry points) */
+int azo_set_weights_device(azg_engine* e, const azg_mlp_desc* d, const float* blob, size_t n_floats) { return azo_set_weights(e, d, blob, n_floats); }
 
 int azo_set_search_index(azg_engine* e, uint32_t idx) { if (!e) return AZG_E_INVALID; e->search_idx = idx; return AZG_OK; }
 
@@ -849,7 +854,7 @@ int azo_selfplay_step(azg_engine* e) {
                 double y;
                 if (e->sp_fs == AZG_FS_MAX_VALUE) y = t->edge_Q[k] / qmax;   /* temperature 1 */
                 else if (e->sp_temperature == 1.0) y = (double)t->edge_n[k] / (double)cmax;
-                else y = pow((double)t->edge_n[k], e->sp_temperature) / pow((double)cmax, e->sp_temperature);   /* = (c/max)^t */
+                else y = pow((double)t->edge_n[k] / (double)cmax, e->sp_temperature);   /* stable_normalizer: (x / max(x)) ** temp, helpers.py:10-27 */
                 pi[a] = y;
                 sum = sum + y;
             }
@@ -916,6 +921,25 @@ int azo_selfplay_ring(azg_engine* e, int32_t* size_steps, int32_t* insert_step, 
 }
 
 /* (host memory here: the oracle has no device) */
+/* azg_results_resident's counterpart: the "device" buffers are host memory owned by the engine */
+int azo_results_resident(azg_engine* e, const float** actions, const int32_t** counts, const double** Q, const double** v_target,
+                         const int32_t** n_children) {
+    if (!e) return AZG_E_INVALID;
+    size_t B = (size_t)e->cfg.n_trees, K = (size_t)e->Kmax;
+    if (!e->res_actions) {
+        e->res_actions = (float*)calloc(B * K, 4); e->res_counts = (int32_t*)calloc(B * K, 4); e->res_Q = (double*)calloc(B * K, 8);
+        e->res_vt = (double*)calloc(B, 8); e->res_nch = (int32_t*)calloc(B, 4);
+    }
+    int rc = azo_results(e, e->res_actions, e->res_counts, e->res_Q, e->res_vt, e->res_nch);
+    if (rc) return rc;
+    if (actions) *actions = e->res_actions;
+    if (counts) *counts = e->res_counts;
+    if (Q) *Q = e->res_Q;
+    if (v_target) *v_target = e->res_vt;
+    if (n_children) *n_children = e->res_nch;
+    return AZG_OK;
+}
+
 int azo_selfplay_rows_device(azg_engine* e, void** ptr, size_t* capacity_rows, size_t* row_len) {
     if (!e || !ptr || !e->sp_on) return AZG_E_STATE;
     *ptr = e->sp_rows;

@@ -37,3 +37,37 @@ def test_multi_rank_loop_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["extra"]["search_only"]["sims_per_s"] >= out["value"] * 0.5
     assert "config D" in out["config"]["workload"]
+
+
+def _bench_json(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("warmup", [3, 4])
+def test_gathered_rows_are_the_previous_steps_rows(warmup):
+    """The two-slot replay ring keeps turning across the warm-up, the timed loop and the collective-free loop; the slot that is
+    all-gathered while step s searches must be the one step s - 1 wrote, whatever the parity of the warm-up (with an
+    odd warm-up the loop used to gather the slot being overwritten).  --verify-gather finds the slot a step wrote by comparing
+    the ring before and after it and checks every gathered block against it."""
+    out = _bench_json(["--gpus", "2", "--steps", "5", "--warmup", str(warmup), "--trees", "256", "--bcast-every", "2", "--backend", "gloo",
+                       "--same-device", "--verify-gather"])
+    assert out["extra"]["collectives"]["gathers_verified"] >= 2 * 5 - 1
+
+
+@pytest.mark.gpu
+def test_config_d_loop_over_rccl_with_one_rank():
+    """The `nccl` branch on hardware: bench.py --config-d under torch.distributed.run with ONE rank -- all_gather_into_tensor on the
+    engine-owned ring (the zero-copy view azg_selfplay_rows_device exports) and the weight broadcast into HBM followed by
+    azg_set_weights_device go through RCCL with world size 1.  Proves RCCL accepts engine-owned memory and that the stream
+    ordering between the engine's stream and RCCL's holds (every gathered block verified), before a multi-GPU node sees it."""
+    out = _bench_json(["--gpus", "1", "--config-d", "--steps", "6", "--warmup", "3", "--trees", "1024", "--bcast-every", "2", "--backend", "nccl",
+                       "--verify-gather"])
+    assert out["n_gpus"] == 1 and "config D" in out["config"]["workload"]
+    c = out["extra"]["collectives"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["gathers_verified"] >= 6 + 3 - 2
+    assert c["weight_sync"].startswith("device to device")
+    assert out["value"] > 0

@@ -50,7 +50,7 @@ def test_mfma_f32_is_a_k_ordered_fma_chain(native):
 
 
 def _kernel_form(e):
-    """What the HIP engine's last search ran as (engine_host.h: 0 search kernel, 1 per-layer launches, 2 team kernel, 3 kernel pair)."""
+    """What the HIP engine's last search ran as (engine_host.h: 0 search kernel, 1 per-layer launches, 2 team kernel)."""
     import ctypes as C
     from alphazero_gym_amd import _native
     return _native.lib().azg_debug_kernel_form(C.c_void_p(e._h.value))
@@ -131,13 +131,13 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2", "pair"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
     instead of LDS, for wide networks (default: the persistent team kernel) the one-launch search kernel and the per-layer
     launches, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
-    itself only for batches of more 16-tree groups than CUs), and the walker + server kernel pair (same condition)."""
+    itself only for batches of more 16-tree groups than CUs)."""
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
     ncomp = extra.pop("_ncomp", 0)
@@ -150,10 +150,6 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         if hidden != [256, 256] or ln or ncomp:
             pytest.skip("the 8-wave workgroups exist for 2x256 Normal / 2-action networks")
         monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
-    if variant == "pair":
-        if hidden not in ([256, 256], [128, 128]) or act not in ("relu", "elu") or ln or ncomp:
-            pytest.skip("the kernel pair exists for 2x256 / 2x128 Normal / 2-action networks")
-        monkeypatch.setenv("AZG_PAIR", "2")
     if variant in ("persistent", "launches"):
         if max(hidden) <= 256:
             pytest.skip("lock-step kernels only exist for hidden widths >= 512")
@@ -179,10 +175,6 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3, forms=forms)
     b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=3)
     _assert_same(a, b)
-    if variant == "pair":
-        # (the pair keeps its trees in LDS with 8-bit ids: at most 255 records and 16 children per node)
-        eligible = a[1]["edge_n"].shape[1] <= 255 and a[0]["counts"].shape[1] <= 16
-        assert forms == ([3] if eligible else [0]), "the search did not run as the walker + server pair"
 
 
 def test_deep_discrete_traces(native):
@@ -355,36 +347,6 @@ def test_config_e_full_size_lockstep(native):
     assert ms < 40.0, f"config E search took {ms:.1f} ms (measured 16.6 ms in round 1)"
 
 
-def test_kernel_pair_gives_up_instead_of_hanging(native, monkeypatch):
-    """The walker + server kernel pair (pair.cuh, AZG_PAIR) needs both kernels resident at once; its waits are bounded the same
-    way as the team kernel's.  Spin limit zero: the pair leaves at its first wait, the engine reruns the search as the
-    one-kernel form under the same search index and stays on it."""
-    import ctypes as C
-    kw = dict(env_id=2, mode=1, n_trees=70, n_sims=30, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=3)
-    desc = _capi.make_desc(3, [256, 256], 2, "elu")
-    blob = O.make_weights(5, 3, [256, 256], 2)
-
-    def run():
-        e = native.HipEngine(**kw)
-        e.set_weights(desc, blob)
-        e.search(e.synthetic_roots())
-        e.search(e.synthetic_roots())
-        out = dict(e.results(), **e.dump_tree())
-        h = C.c_void_p(e._h.value)
-        n, form = native.lib().azg_debug_team_fallbacks(h), native.lib().azg_debug_kernel_form(h)
-        e.close()
-        return out, n, form
-
-    monkeypatch.setenv("AZG_PAIR", "2")
-    ref, n, form = run()
-    assert (n, form) == (0, 3)
-    monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
-    out, n, form = run()
-    assert (n, form) == (1, 0)
-    for k in ref:
-        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
-
-
 def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
     """The persistent team kernel's waits are bounded (its workgroups must all be resident: another process on the GPU can
     prevent that).  With a spin limit of zero every wait counts as timed out: the launch leaves, the engine notices, redoes the
@@ -536,3 +498,83 @@ def _timed_ms(e):
     e.search_resident()
     e.sync()
     return e.last_search_ms()
+
+
+class _DevArr:
+    """A raw device pointer as a CUDA-array-interface object (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+@pytest.mark.parametrize("hidden,act,ln,ncomp", [([256, 256], "elu", False, 0), ([1024] * 4, "elu", False, 0), ([100, 60], "relu", True, 0),
+                                                 ([128, 128, 128], "elu", False, 2)])
+def test_device_side_weight_sync_equals_the_host_path(native, hidden, act, ln, ncomp):
+    """azg_set_weights_device (blob in HBM, re-layout by the engine's gather kernel) against azg_set_weights (host blob): the same
+    network -- identical azg_mlp_eval outputs and identical trees -- also after a second, different blob through the cached map."""
+    import torch
+    n_dist = 3 * ncomp if ncomp else 2
+    desc = _capi.make_desc(3, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
+    kw = dict(env_id=2, mode=1, n_trees=40, n_sims=12, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=9)
+    host, dev = native.HipEngine(**kw), native.HipEngine(**kw)
+    roots = host.synthetic_roots()
+    obs = np.random.Generator(np.random.PCG64(3)).uniform(-1, 1, (50, 3)).astype(np.float32)
+    for wseed in (5, 6):
+        blob = O.make_weights(wseed, 3, hidden, n_dist, scale=2.0)
+        if ln:
+            blob = O.add_layernorm(blob, 3, hidden, n_dist, 7)
+        host.set_weights(desc, blob)
+        d_blob = torch.from_numpy(blob).cuda()
+        torch.cuda.synchronize()
+        dev.set_weights_device(desc, d_blob.data_ptr(), d_blob.numel())
+        d_blob.zero_()                                                # the engine keeps its own copy
+        for a, b in zip(host.mlp_eval(obs), dev.mlp_eval(obs)):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        host.search(roots); dev.search(roots)
+        _assert_same((host.results(), host.dump_tree(), host.root_eval()), (dev.results(), dev.dump_tree(), dev.root_eval()))
+    host.close(); dev.close()
+
+
+def test_set_policy_with_parameters_on_the_gpu_takes_the_device_path(native, monkeypatch):
+    """Engine.set_policy with a torch policy living on the engine's GPU flattens it there and calls azg_set_weights_device; the
+    result equals the host path's (policy_blob + azg_set_weights)."""
+    import torch
+    from alphazero_gym_amd.network.policies import make_policy
+    torch.manual_seed(4)
+    pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=[256, 256], nonlinearity="elu",
+                      num_components=1, action_bound=2.0)
+    kw = dict(env_id=2, mode=1, n_trees=20, n_sims=10, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=9)
+    host, dev = native.HipEngine(**kw), native.HipEngine(**kw)
+    host.set_policy(pol)                                              # CPU parameters: host path
+    calls = []
+    orig = dev.set_weights_device
+    monkeypatch.setattr(dev, "set_weights_device", lambda *a: (calls.append(a[2]), orig(*a))[1])
+    dev.set_policy(pol.cuda())
+    assert calls == [sum(p.numel() for p in pol.parameters())]
+    roots = host.synthetic_roots()
+    host.search(roots); dev.search(roots)
+    _assert_same((host.results(), host.dump_tree(), host.root_eval()), (dev.results(), dev.dump_tree(), dev.root_eval()))
+    host.close(); dev.close()
+
+
+def test_results_resident_hands_out_the_same_numbers_without_a_copy(native):
+    """azg_results_resident: return_results (mcts.py:269-307) into the engine's device buffers, wrapped as torch tensors through
+    the CUDA array interface: same values as the host download of azg_results."""
+    import torch
+    kw = dict(env_id=2, mode=1, n_trees=300, n_sims=40, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=9)
+    e = native.HipEngine(**kw)
+    e.set_weights(_capi.make_desc(3, [64, 64], 2, "elu"), O.make_weights(5, 3, [64, 64], 2))
+    e.upload_roots(e.synthetic_roots())
+    e.search_resident()
+    p = e.results_resident()                                          # launches only
+    e.sync()
+    B, K = e.n_trees, e.kmax
+    got = {"actions": torch.as_tensor(_DevArr(p["actions"], (B, K), "<f4"), device="cuda"),
+           "counts": torch.as_tensor(_DevArr(p["counts"], (B, K), "<i4"), device="cuda"),
+           "Q": torch.as_tensor(_DevArr(p["Q"], (B, K), "<f8"), device="cuda"),
+           "v_target": torch.as_tensor(_DevArr(p["v_target"], (B,), "<f8"), device="cuda"),
+           "n_children": torch.as_tensor(_DevArr(p["n_children"], (B,), "<i4"), device="cuda")}
+    want = e.results()
+    for k in want:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=k)
+    e.close()

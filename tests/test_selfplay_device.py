@@ -196,6 +196,14 @@ def test_selfplay_variants_hip_matches_oracle_bit_for_bit(name):
     assert out[0][2] == out[1][2]
 
 
+def _host_ring(ptr, shape, device):
+    """The CPU oracle standing in for the engine: its "device" pointer is host memory (test double, injected from here)."""
+    import ctypes
+    import torch
+    buf = (ctypes.c_float * (shape[0] * shape[1])).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.float32).reshape(shape))
+
+
 @pytest.mark.parametrize("which", ENGINES)
 def test_device_replay_samples_like_the_reference_buffer(which):
     """DeviceReplay = the ring + the reference's minibatch rule (buffers.py:84-123), pinned by the T6 golden: same shuffles under
@@ -212,7 +220,7 @@ def test_device_replay_samples_like_the_reference_buffer(which):
         full.selfplay_step()
         ring.selfplay_step()
     all_rows = full.selfplay_rows(clear=False)
-    rep = DeviceReplay(ring, batch_size=3, device="cpu" if which == "oracle" else None)
+    rep = DeviceReplay(ring, batch_size=3, **(dict(device="cpu", wrap=_host_ring) if which == "oracle" else {}))
     assert len(rep) == 7 and (rep.rows().is_cuda == (which == "hip"))
     np.testing.assert_array_equal(rep.rows().cpu().numpy(), ring.selfplay_rows(clear=False))      # zero-copy view == download
     np.random.seed(123)
@@ -229,6 +237,11 @@ def test_device_replay_samples_like_the_reference_buffer(which):
     before = rep.rows().clone()
     ring.selfplay_step()
     assert not torch.equal(before, rep.rows())
+    # a second selfplay_begin replaces the ring: the view follows it instead of dangling
+    ring.selfplay_begin(case["max_len"], capacity_steps=3, fifo=True)
+    ring.selfplay_step()
+    assert len(rep) == 1 and rep.ring.shape[0] == 3
+    np.testing.assert_array_equal(rep.rows().cpu().numpy(), ring.selfplay_rows(clear=False))
     full.close(); ring.close()
 
 
