@@ -24,7 +24,11 @@ static hipError_t launch_g(azg_engine* e) {
         static_lds = (int)fa.sharedSizeBytes;
         static_lds_cache.store(static_lds, std::memory_order_relaxed);
     }
-    const LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, ENV != AZG_ENV_CARTPOLE, TLDS);
+    // discrete LDS trees: the expanded nodes' env states go to LDS too when the CU has room for them
+    constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
+    LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 1);
+    e->P.lds_state = (!CONT && TLDS != TS_GLOBAL && L.total + (size_t)static_lds <= 160 * 1024 && !getenv("AZG_NO_LDS_STATE")) ? 1 : 0;
+    if (!e->P.lds_state) L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 0);
     if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
     if (L.total > 48 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);

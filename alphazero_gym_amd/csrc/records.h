@@ -105,6 +105,7 @@ struct KParams {
     int Htrue[MAX_STREAM_LAYERS];          // true (unpadded) width of trunk layer l
     const f32x4* lng[MAX_STREAM_LAYERS];   // LayerNorm weight of trunk layer l, [HP/16][64] (D-register layout, zero padded)
     const f32x4* lnb[MAX_STREAM_LAYERS];   // LayerNorm bias
+    int lds_state;              // discrete LDS trees: the env states of expanded nodes live in LDS too (set by the launch planning)
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };
 

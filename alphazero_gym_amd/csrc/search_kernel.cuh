@@ -15,15 +15,19 @@
 struct LdsLayout {
     size_t act_off;    // activation buffers: nbuf x NG groups x HP*64 bytes
     size_t tree_off;   // (TLDS) per-tree regions
-    size_t per_tree;   // bytes per tree: R records of 16 B + child-list pool (continuous) or R priors (discrete)
+    size_t per_tree;   // bytes per tree: R records of 16 B + child-list pool (continuous) or R priors (discrete) (+ env states)
+    size_t state_off;  // offset of a tree's env-state slots inside its region (0: none)
     size_t total;
 };
-__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, int tlds) {
+// lds_state (discrete LDS trees): n_sims + 1 slots of 4 doubles per tree for the env states of the expanded nodes
+__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, int tlds, int lds_state = 0) {
     LdsLayout L;
     L.act_off = ((size_t)tab_n * 8 + (size_t)(n_sims + 2) * 2 + 15) / 16 * 16;
     L.tree_off = L.act_off + (size_t)nbuf * NG * HP * 64;
     L.per_tree = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * (tlds == TS_LDS9 ? 8 : 4) : (size_t)R * 4);   // 4 ids per pool unit
     L.per_tree = (L.per_tree + 15) / 16 * 16;
+    L.state_off = 0;
+    if (lds_state && !cont && tlds != TS_GLOBAL) { L.state_off = L.per_tree; L.per_tree += (size_t)(n_sims + 1) * 32; }
     L.total = L.tree_off + (tlds != TS_GLOBAL ? L.per_tree * 16 * NG : 0);
     return L;
 }
@@ -46,14 +50,13 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int sub = lane & 15;
-    const bool has_tree = (lane >> 4) < TPV;
-    const int tl = has_tree ? wave * TPV + (lane >> 4) : 0;   // tree within the workgroup
-    const int tree = blockIdx.x * TPW + tl;
-    const bool live = has_tree && tree < P.B;
-    const unsigned gtree = (unsigned)(P.tree_base + tree);
-
-    const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS);
+    // Two waves per SIMD (NW = 8) leave each wave 256 registers, 128 of them weights: nothing that can be re-derived in a few
+    // instructions is carried across the network phase there.  The per-tree context (indices, global base pointers, LDS bases)
+    // is rebuilt from the thread index at the top of every tree phase, the loop-carried tree state crosses the network phase
+    // packed two fields to a register, and the path's rewards / returns are fetched after the network phase instead of during
+    // the descent.  With one wave per SIMD (NW = 4: 512 registers) everything stays in registers (measured faster there).
+    constexpr bool LEAN = (NW == 8);
+    const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS, P.lds_state);
     double* s_sqrt = s_dyn;
     unsigned short* s_pw = (unsigned short*)(s_dyn + P.tab_n);   // widening thresholds, clamped (a node has < 32768 children)
     f32x4* s_actA = (f32x4*)((char*)s_dyn + L.act_off);
@@ -87,30 +90,47 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
         for (int i = 0; i < NTW; ++i) wr.wh[i] = P.Whead[(wave * NTW + i) * 64 + lane];
     }
 
-    const size_t tb = (size_t)(live ? tree : 0) * P.R;
-    Cold* cold = P.cold + tb;
-    double* edge_W = P.edge_W + tb;
-    float* action = P.action + tb;
-    TreeStore<TLDS> ts;
-    if constexpr (TLDS != TS_GLOBAL) {
-        // per tree: R records of 16 B, then (continuous) the child-list pool or (discrete) R priors
-        char* base = (char*)s_dyn + L.tree_off + L.per_tree * tl;
-        ts.hot = (Rec*)base;
-        ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
-        ts.prior = (float*)(base + (size_t)P.R * 16);
-    } else {
-        ts.hot = (Rec*)(P.hot + tb);
-        ts.child = P.child + tb * P.Kp;
-        ts.prior = P.prior + tb;
-    }
-    const f32x4* my_parts = s_parts + (tl >> 4) * NCH * PSTR;   // the head partials of this tree's group
+    // everything a tree phase needs to know about "its" tree, as a function of the thread index
+    struct Ctx {
+        int sub, tl, tree; bool has_tree, live; unsigned gtree; size_t tb;
+        Cold* cold; double* edge_W; float* action; TreeStore<TLDS> ts; const f32x4* my_parts;
+    };
+    auto make_ctx = [&](int t) {
+        Ctx c;
+        const int w = t >> 6, ln = t & 63;
+        c.sub = ln & 15;
+        c.has_tree = (ln >> 4) < TPV;
+        c.tl = c.has_tree ? w * TPV + (ln >> 4) : 0;   // tree within the workgroup
+        c.tree = blockIdx.x * TPW + c.tl;
+        c.live = c.has_tree && c.tree < P.B;
+        c.gtree = (unsigned)(P.tree_base + c.tree);
+        c.tb = (size_t)(c.live ? c.tree : 0) * P.R;
+        c.cold = P.cold + c.tb;
+        c.edge_W = P.edge_W + c.tb;
+        c.action = P.action + c.tb;
+        if constexpr (TLDS != TS_GLOBAL) {
+            // per tree: R records of 16 B, then (continuous) the child-list pool or (discrete) R priors
+            char* base = (char*)s_dyn + L.tree_off + L.per_tree * c.tl;
+            c.ts.hot = (Rec*)base;
+            c.ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
+            c.ts.prior = (float*)(base + (size_t)P.R * 16);
+            c.ts.state = L.state_off ? (double*)(base + L.state_off) : nullptr;
+        } else {
+            c.ts.hot = (Rec*)(P.hot + c.tb);
+            c.ts.child = P.child + c.tb * P.Kp;
+            c.ts.prior = P.prior + c.tb;
+        }
+        c.my_parts = s_parts + (c.tl >> 4) * NCH * PSTR;   // the head partials of this tree's group
+        return c;
+    };
+    Ctx cx = make_ctx(tid);
 
 #ifdef AZG_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     TreeState st = {};
     st.need_eval = false;
-    if (has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, s_obsT);
+    if (cx.has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tree, cx.live, cx.sub, cx.tl, cx.gtree, s_obsT);
     __syncthreads();
 
     for (int sim = -1; sim < P.n_sims; ++sim) {
@@ -120,20 +140,42 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
         // terminal (rare; its outputs are then ignored): testing for that costs two more barriers per step (__syncthreads_or)
         __syncthreads();
         STAMP(t_b);
+        unsigned pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;
+        int tid_o = tid;
+        if constexpr (LEAN) {
+            // the loop-carried tree state, two fields to a register (record ids, depths, pool units: all < 65536 in LDS trees)
+            pk0 = (unsigned)st.nrec | ((unsigned)st.leaf << 16);
+            pk1 = (unsigned)st.path_D | ((unsigned)st.kbase << 16);
+            pk2 = (unsigned)(st.my_depth + 1) | ((unsigned)st.pid << 16);
+            pk3 = (unsigned)st.ptop | ((unsigned)st.need_eval << 16);
+            asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3));
+        }
 #ifdef AZG_STAMPS
         mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
         mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
+        if constexpr (LEAN) {
+            // opaque to the optimiser: whatever is derived from these is computed HERE, not kept alive across the network phase
+            asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3), "+v"(tid_o));
+            st.nrec = (int)(pk0 & 0xffffu); st.leaf = (int)(pk0 >> 16);
+            st.path_D = (int)(pk1 & 0xffffu); st.kbase = (int)(pk1 >> 16);
+            st.my_depth = (int)(pk2 & 0xffffu) - 1; st.pid = (int)(pk2 >> 16);
+            st.ptop = (int)(pk3 & 0xffffu); st.need_eval = (pk3 >> 16) != 0;
+            cx = make_ctx(tid_o);
+            // the path's rewards and cumulative returns (the descent did not fetch them: tree_phase_b<..., FETCH = false>)
+            st.pr = 0.0; st.pW = 0.0;
+            if (cx.live && sim >= 0 && st.my_depth >= 1) { st.pr = cx.cold[st.pid].r; st.pW = cx.edge_W[st.pid]; }
+        }
         // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl & 15, gtree, my_parts, s_bhead, s_sqrt);
+        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl & 15, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
         STAMP(t_d);
         // ================= tree phase B: next trace: select down, step the env, expand =================
         st.need_eval = false;
-        if (live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short>(P, st, ts, cold, edge_W, action, tb, sub, tl, gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+        if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
         __threadfence_block();
         STAMP(t_e);
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase
@@ -142,6 +184,10 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
         STAMP_ADD(3, t_d, t_e);   // select / step / expand
     }
     const int nrec = st.nrec;
+    const int sub = cx.sub, tree = cx.tree;
+    const bool live = cx.live;
+    const size_t tb = cx.tb;
+    const TreeStore<TLDS>& ts = cx.ts;
 #ifdef AZG_STAMPS
     if (lane == 0) for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * NW + wave) * 16 + i] = st_acc[i];
 #endif

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
         ts.hot = (Rec*)base;
         ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
         ts.prior = (float*)(base + (size_t)P.R * 16);
+        ts.state = nullptr;
     } else {
         ts.hot = (Rec*)(P.hot + tb);
         ts.child = P.child + tb * P.Kp;

@@ -109,6 +109,11 @@ template <typename RecT, typename IdT> struct TreeStoreLds {
     typedef RecT Rec;
     typedef IdT PoolId;
     Rec* hot; IdT* pool; float* prior;
+    // discrete mode, when the CU's LDS has room (search_kernel.cuh: lds_layout): the env state (4 doubles) of every expanded,
+    // non-terminal node, slot (first - 1) / A of the node whose child edges start at record `first` -- a node gets its A edges
+    // when it is evaluated, so the e-th evaluated node of a tree (the root is the 0-th) owns slot e; a node that is being created
+    // while the tree holds nrec records will be the ((nrec - 1) / A)-th.  nullptr: the states are read from the cold records.
+    double* state;
     __device__ __forceinline__ int child_at(int, const Rec& hp, int i, int) const {
         return hp.n_child == 1 ? (int)hp.first : (int)pool[4 * (int)hp.cbase + i];
     }
@@ -136,6 +141,7 @@ template <> struct TreeStore<TS_LDS9> : TreeStoreLds<RecM, unsigned short> {};
 template <> struct TreeStore<TS_GLOBAL> {
     typedef RecL Rec;
     Rec* hot; unsigned short* child; float* prior;
+    static constexpr double* state = nullptr;   // (global trees keep env states in their cold records)
     __device__ __forceinline__ int child_at(int p, const Rec&, int i, int Kp) const { return (int)child[p * Kp + i]; }
     __device__ __forceinline__ void child_append(int p, const Rec&, int K, int id, int&, bool writer, int Kp) const {
         if (writer) {
@@ -167,15 +173,14 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
     while (true) {
         int mine = 0, cnt = 0, jj = j;
         bool hit_root = false;
-        Rec mrec = ts.hot[jj];
 #pragma unroll 1
         for (int d = 0; d < 16; ++d) {
-            Rec rr = ts.hot[jj];
-            if (sub == d) { mine = jj; mrec = rr; }
+            if (sub == d) mine = jj;
             cnt = d + 1;
             if (jj == 0) { hit_root = true; break; }
-            jj = rr.parent;
+            jj = ts.hot[jj].parent;
         }
+        Rec mrec = ts.hot[mine];   // (read once the lane knows its record: a record carried through the loop lives in scratch memory)
         const bool is_edge = (sub < cnt) && (mine != 0);
         double r = 0.0, W = 0.0;
         if (is_edge) { r = cold[mine].r; W = edge_W[mine]; }

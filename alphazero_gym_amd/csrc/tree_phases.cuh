@@ -172,6 +172,12 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
             cold[0] = c;
             edge_W[0] = 0.0;
             if (CONT) action[0] = 0.0f;
+            if constexpr (!CONT && TLDS != TS_GLOBAL) {
+                if (ts.state) {   // the root will be the first node to be evaluated: slot 0
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ts.state[k] = rs[k];
+                }
+            }
         }
         if (sub < 4) obsT[sub * TPW + tl] = live ? obs[sub] : 0.0f;
 }
@@ -298,7 +304,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 
 // Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
 // step the environment and create the node (expansion: mcts.py:216-238); leaves the new leaf's observation in obsT.
-template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int>
+// FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM) {
@@ -312,7 +319,11 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     }
     int p = 0;
     Rec hp = ts.hot[0];
-    Cold cp = cold[0];   // cold part of the current node, prefetched one level ahead
+    Cold cp;             // cold part of the current node, prefetched one level ahead
+    bool from_cold = true;
+    if constexpr (!CONT && TLDS != TS_GLOBAL) from_cold = (ts.state == nullptr);   // (LDS-resident env states: read after the descent)
+    if (from_cold) cp = cold[0];
+    else { cp.s[0] = cp.s[1] = cp.s[2] = cp.s[3] = 0.0; }
     st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
     int chosen = 0;
     bool widen = false, hit_terminal = false;
@@ -349,7 +360,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             st.my_depth = st.path_D; st.pid = chosen;
             // continuous mode (2-3 levels, a slow scored descent): fetched here, in the shadow of the level's LDS waits;
             // discrete mode (8-9 levels of pointer chasing): all levels at once after the loop (measured both ways)
-            if (CONT) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
+            if (CONT && FETCH) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
         }
         if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
             if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
@@ -357,7 +368,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         // the node's env state for the step that follows if the trace leaves the tree here: requested at every level, the wave
         // waits only for the last one (Pendulum: the whole cold record, its widening needs the cached policy too)
         if (CONT) cp = cold[p];
-        else { cp.s[0] = cold[p].s[0]; cp.s[1] = cold[p].s[1]; cp.s[2] = cold[p].s[2]; cp.s[3] = cold[p].s[3]; }
+        else if (from_cold) { cp.s[0] = cold[p].s[0]; cp.s[1] = cold[p].s[1]; cp.s[2] = cold[p].s[2]; cp.s[3] = cold[p].s[3]; }
+        // (LDS-resident env states: read once, below, for the node the trace leaves the tree from)
         STAMP(tl4);
         STAMP_ADD(8, tl0, tl2);    // whole selection of a level (scores + arg-max)
         STAMP_ADD(9, tl2, tl3);    // chosen record
@@ -367,7 +379,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st_acc[12] += 1;
 #endif
     }
-    if (!CONT && st.my_depth >= 1) { st.pr = cold[st.pid].r; st.pW = edge_W[st.pid]; }   // (consumed after the network phase: latency hidden)
+    if (!CONT && FETCH && st.my_depth >= 1) { st.pr = cold[st.pid].r; st.pW = edge_W[st.pid]; }   // (consumed after the network phase: latency hidden)
     STAMP(tb1);
     STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {
@@ -406,6 +418,13 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
             r = r / P.reward_scale;   // mcts.py:687
         } else {
+            if constexpr (TLDS != TS_GLOBAL) {
+                if (ts.state) {
+                    const int slot = P.A == 2 ? ((int)hp.first - 1) >> 1 : ((int)hp.first - 1) / P.A;
+                    const double* sp = ts.state + 4 * slot;
+                    cp.s[0] = sp[0]; cp.s[1] = sp[1]; cp.s[2] = sp[2]; cp.s[3] = sp[3];
+                }
+            }
             cartpole_step(cp.s, chosen - (int)hp.first, ns, &r, &done);
         }
         float obs[4];
@@ -415,9 +434,18 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
 #pragma unroll
             for (int k = 0; k < 4; ++k) c.s[k] = k < S ? ns[k] : 0.0;
             if (CONT) c.s[2] = sn;
-            c.r = r; c.V = 0.0f; c.mu = 0.0f; c.sg = 0.0f; c.pad = 0.0f;
+            float zero = 0.0f;
+            asm volatile("" : "+v"(zero));   // (made here: a zero vector kept in registers for the whole search costs four of them)
+            c.r = r; c.V = zero; c.mu = zero; c.sg = zero; c.pad = zero;
             cold[chosen] = c;
             ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+            if constexpr (!CONT && TLDS != TS_GLOBAL) {
+                if (ts.state && !done) {   // the next node to be evaluated in this tree: its edges will start at record nrec
+                    double* sp = ts.state + 4 * (P.A == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sp[k] = ns[k];
+                }
+            }
         }
         if (sub == (st.path_D & 15)) { st.my_depth = st.path_D; st.pid = chosen; st.pr = r; st.pW = 0.0; }
         st.leaf = chosen;

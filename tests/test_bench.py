@@ -55,7 +55,7 @@ def test_gathered_rows_are_the_previous_steps_rows(warmup):
     the ring before and after it and checks every gathered block against it."""
     out = _bench_json(["--gpus", "2", "--steps", "5", "--warmup", str(warmup), "--trees", "256", "--bcast-every", "2", "--backend", "gloo",
                        "--same-device", "--verify-gather"])
-    assert out["extra"]["collectives"]["gathers_verified"] >= 2 * 5 - 1
+    assert out["extra"]["collectives"]["gathers_verified"] >= warmup + 5 - 2   # (a run of k steps gathers k blocks)
 
 
 @pytest.mark.gpu
