@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
             pk0 = (unsigned)st.nrec | ((unsigned)st.leaf << 16);
             pk1 = (unsigned)st.path_D | ((unsigned)st.kbase << 16);
             pk2 = (unsigned)(st.my_depth + 1) | ((unsigned)st.pid << 16);
-            pk3 = (unsigned)st.ptop | ((unsigned)st.need_eval << 16);
+            pk3 = (unsigned)st.ptop | ((unsigned)st.need_eval << 16) | ((unsigned)st.resume << 20);
             asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3));
         }
 #ifdef AZG_STAMPS
@@ -162,20 +162,20 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
             st.nrec = (int)(pk0 & 0xffffu); st.leaf = (int)(pk0 >> 16);
             st.path_D = (int)(pk1 & 0xffffu); st.kbase = (int)(pk1 >> 16);
             st.my_depth = (int)(pk2 & 0xffffu) - 1; st.pid = (int)(pk2 >> 16);
-            st.ptop = (int)(pk3 & 0xffffu); st.need_eval = (pk3 >> 16) != 0;
+            st.ptop = (int)(pk3 & 0xffffu); st.need_eval = ((pk3 >> 16) & 1u) != 0; st.resume = (int)(pk3 >> 20);
             cx = make_ctx(tid_o);
             // the path's rewards and cumulative returns (the descent did not fetch them: tree_phase_b<..., FETCH = false>)
             st.pr = 0.0; st.pW = 0.0;
             if (cx.live && sim >= 0 && st.my_depth >= 1) { st.pr = cx.cold[st.pid].r; st.pW = cx.edge_W[st.pid]; }
         }
         // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl & 15, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl & 15, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
         STAMP(t_d);
         // ================= tree phase B: next trace: select down, step the env, expand =================
         st.need_eval = false;
-        if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+        if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
         __threadfence_block();
         STAMP(t_e);
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase

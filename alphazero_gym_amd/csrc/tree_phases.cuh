@@ -18,6 +18,7 @@ struct TreeState {
     int kbase;            // progressive-widening noise cache: lane `sub` holds the N(0,1) draw of record kbase + sub
     float eps_c;          // per lane
     int ptop;             // LDS trees: next free 4-byte unit of the child-list pool
+    int resume;           // discrete mode with cached selections: depth at which the next descent leaves the path of this trace (0: the root)
 };
 
 // ---- the cached selection of a node ("best"): the child the next descent through the node will take.
@@ -125,7 +126,7 @@ __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<T
 // record `pid`): the lane reads its node and the node's two children, scores both and stores the winner's index -- no
 // cross-lane traffic at all.  `mine`: the lane's slot holds a node of this path above the leaf.
 template <int ENV, int TLDS>
-__device__ __forceinline__ void refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt) {
+__device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int p = mine ? pid : 0;
     const Rec hp = ts.hot[p];
@@ -138,7 +139,9 @@ __device__ __forceinline__ void refresh_best_own_slot(const KParams& P, const Tr
     const double U0 = h0.Q + (double)pc0 * tree_div(sq, (double)((int)h0.edge_n + 1));
     const double U1 = h1.Q + (double)pc1 * tree_div(sq, (double)((int)h1.edge_n + 1));
     // the first child unless the second is strictly larger (argmax2_payload's rule)
-    if (mine) set_best<false>(&ts.hot[p], hp, c0 + (U0 >= U1 ? 0 : 1));
+    const int win = c0 + (U0 >= U1 ? 0 : 1);
+    if (mine) set_best<false>(&ts.hot[p], hp, win);
+    return win;   // (the node's selection: the record the next descent through it takes)
 }
 
 // initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
@@ -151,7 +154,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
     st.path_D = 0; st.my_depth = -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
-    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0;
+    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0; st.resume = 0;
     if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
         double rs[S], sn;
 #pragma unroll
@@ -185,7 +188,8 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 // Phase A: give the evaluated leaf its value / policy (evaluation, add_value_estimate: mcts.py:385-416, 602-623; the root's first
 // action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase
 // for the tree's group of 16 (PSTR entries per chunk), tl = the tree's column in that group.
-template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64>
+// RESUME (discrete mode, cached selections): also work out where the next descent leaves this trace's path (st.resume).
+template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
                                              const float* bhead, const double* s_sqrt) {
@@ -293,7 +297,18 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 if (!TLDS) __threadfence_block();
                 if (P.A == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
-                    refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, st.my_depth >= lo && st.my_depth < D, s_sqrt);
+                    const bool mine = st.my_depth >= lo && st.my_depth < D;
+                    const int win = refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, mine, s_sqrt);
+                    if constexpr (RESUME) {
+                        // The next trace follows the stored selections from the root: it walks this trace's path for as long as every
+                        // node's (re-taken) selection is still the path's next record, i.e. down to the shallowest node whose
+                        // selection moved away -- or to the path's end.  Paths of up to 15 levels have depth d in slot d: lane
+                        // order = depth order, so the shallowest such node is the row's lowest lane that votes.
+                        const int next_pid = dpp_i32<DPP_ROW_ROR15>(st.pid);   // the record in the slot of depth + 1
+                        const unsigned long long votes = __ballot(mine && win != next_pid);
+                        const unsigned row = (unsigned)(votes >> (threadIdx.x & 48)) & 0xffffu;   // the 16 lanes of this tree
+                        st.resume = D < 16 ? (row ? __builtin_ctz(row) : D) : 0;
+                    }
                 } else {
                     for (int d = D - 1; d >= lo; --d) refresh_best<ENV, TLDS>(P, ts, __shfl(st.pid, d & 15, 16), sub, s_sqrt);
                 }
@@ -305,7 +320,9 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 // Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
 // step the environment and create the node (expansion: mcts.py:216-238); leaves the new leaf's observation in obsT.
 // FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
-template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true>
+// RESUME (discrete mode, cached selections): the descent starts where the last trace's path is left (st.resume, set by
+// tree_phase_a<..., RESUME = true>) instead of at the root; the path slots above that depth are still in the lanes.
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM) {
@@ -318,17 +335,29 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
     }
     int p = 0;
-    Rec hp = ts.hot[0];
+    bool resumed = false;
+    if constexpr (RESUME && !CONT) {
+        if (P.epsilon == 0.0 && P.A == 2 && st.resume > 0) {
+            // same path as a descent from the root down to depth `resume` (tree_phase_a): go on from that node
+            resumed = true;
+            p = __shfl(st.pid, st.resume, 16);
+            if (st.my_depth > st.resume) st.my_depth = -1;   // the slots below it belong to the old trace
+            st.path_D = st.resume;
+        }
+    }
+    Rec hp = ts.hot[p];
     Cold cp;             // cold part of the current node, prefetched one level ahead
     bool from_cold = true;
     if constexpr (!CONT && TLDS != TS_GLOBAL) from_cold = (ts.state == nullptr);   // (LDS-resident env states: read after the descent)
-    if (from_cold) cp = cold[0];
+    if (from_cold) cp = cold[p];   // (p: the root, or the node a resumed descent starts from)
     else { cp.s[0] = cp.s[1] = cp.s[2] = cp.s[3] = 0.0; }
-    st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
+    if (!resumed) { st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; }
+    st.pr = 0.0; st.pW = 0.0;
     int chosen = 0;
     bool widen = false, hit_terminal = false;
+    if constexpr (RESUME && !CONT) hit_terminal = resumed && (hp.flags & FLAG_TERMINAL);   // (the old trace ended in a terminal node and nothing moved)
     STAMP(tb0);
-    while (true) {
+    while (!hit_terminal) {
         STAMP(tl0);
         const int K = hp.n_child;
         if (CONT) {
