@@ -18,9 +18,10 @@ AZG_E_DEVICE = -3
 AZG_E_STATE = -4
 AZG_E_UNSUPPORTED = -5
 
-ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1 = 0, 1, 2
+ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1, ENV_MOUNTAINCAR = 0, 1, 2, 3
 MODE_DISCRETE, MODE_CONTINUOUS = 0, 1
 VT = {"off_policy": 0, "on_policy": 1, "greedy": 2}
+TIE = {"first": 0, "random": 1}   # helpers.argmax on exactly equal scores: lowest index (parity) or a Philox-keyed uniform pick
 ACT = {"relu": 0, "elu": 1, "leakyrelu": 2, "relu6": 3, "silu": 4, "swish": 4, "hardswish": 5}
 _ACT_MODULES = {"ReLU": 0, "ELU": 1, "LeakyReLU": 2, "ReLU6": 3, "SiLU": 4, "Hardswish": 5}
 MAX_HIDDEN = 8
@@ -39,7 +40,7 @@ class AzgConfig(C.Structure):
         ("num_actions", C.c_int32),
         ("v_target", C.c_int32),
         ("tree_id_base", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("tie_break", C.c_int32),
         ("c_uct", C.c_double),
         ("gamma", C.c_double),
         ("epsilon", C.c_double),
@@ -214,7 +215,7 @@ class Engine:
 
     def __init__(self, fns, *, env_id, mode, n_trees, n_sims, c_uct, gamma, epsilon=0.0, num_actions=0, c_pw=1.0,
                  kappa=0.5, v_target="off_policy", reward_scale=PENDULUM_R_SCALE, action_bound=2.0, seed=34,
-                 tree_id_base=0, device_id=0):
+                 tree_id_base=0, device_id=0, tie_break="first"):
         self._f = fns
         self._h = C.c_void_p()
         cfg = AzgConfig()
@@ -227,6 +228,7 @@ class Engine:
         cfg.num_actions = num_actions
         cfg.v_target = VT[v_target] if isinstance(v_target, str) else v_target
         cfg.tree_id_base = tree_id_base
+        cfg.tie_break = TIE[tie_break] if isinstance(tie_break, str) else int(tie_break)
         cfg.c_uct = float(c_uct)
         cfg.gamma = float(gamma)
         cfg.epsilon = float(epsilon)

@@ -160,12 +160,15 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(nullptr, AZG_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > 2) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
-    if (cfg->mode == AZG_MODE_DISCRETE && cfg->env_id != AZG_ENV_CARTPOLE)
-        return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole)");
-    if (cfg->mode == AZG_MODE_CONTINUOUS && cfg->env_id == AZG_ENV_CARTPOLE)
+    if (cfg->env_id < 0 || cfg->env_id > 3) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
+    const bool discrete_env = cfg->env_id == AZG_ENV_CARTPOLE || cfg->env_id == AZG_ENV_MOUNTAINCAR;
+    if (cfg->mode == AZG_MODE_DISCRETE && !discrete_env)
+        return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole, MountainCar)");
+    if (cfg->mode == AZG_MODE_CONTINUOUS && discrete_env)
         return fail(nullptr, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
-    if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != 2) return fail(nullptr, AZG_E_INVALID, "CartPole has num_actions == 2");
+    if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != (cfg->env_id == AZG_ENV_CARTPOLE ? 2 : 3))
+        return fail(nullptr, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3)");
+    if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(nullptr, AZG_E_INVALID, "unknown tie_break");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_E_DEVICE, "no HIP device available");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, AZG_E_DEVICE, "device_id out of range");
@@ -191,7 +194,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
-    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 3;
+    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : (cfg->env_id == AZG_ENV_MOUNTAINCAR ? 2 : 3);
     const int ns = cfg->n_sims;
     std::vector<int> pw(ns + 2, 0);
     if (cfg->mode == AZG_MODE_CONTINUOUS) {
@@ -212,6 +215,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
         e->nd = cfg->num_actions;
     }
     if (e->R > 32767) { delete e; return fail(nullptr, AZG_E_UNSUPPORTED, "tree too large: records per tree must be < 32768"); }
+    if (cfg->tie_break == AZG_TIE_RANDOM && e->Kmax > 16) { delete e; return fail(nullptr, AZG_E_UNSUPPORTED, "tie_break random supports at most 16 children per node"); }
     e->Kp = (e->Kmax + 15) / 16 * 16;
     // sqrt(n+1) table: node visit counts reach n_sims (+ the carried root count in discrete mode; beyond 3 n_sims the kernel
     // computes the root's square root in place)
@@ -265,7 +269,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     HK(hipMemset(hot, 0, B * R * sizeof(RecL)));
     HK(hipMemset(e->d_carry, 0, B * sizeof(int)));
     P.B = cfg->n_trees; P.n_sims = ns; P.R = e->R; P.Kp = e->Kp; P.A = cfg->num_actions; P.nd = e->nd;
-    P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
+    P.tie_random = cfg->tie_break == AZG_TIE_RANDOM; P.env_id = cfg->env_id; P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
     P.c_uct = cfg->c_uct; P.gamma = cfg->gamma; P.epsilon = cfg->epsilon; P.reward_scale = cfg->reward_scale;
     P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;
     P.seed = cfg->seed; P.S = e->S_env; P.tab_n = e->tab_n;
@@ -531,6 +535,11 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
             if ((s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr))
                 return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         }
+    } else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) {
+        for (int i = 0; i < B; ++i) {
+            const double* s = roots + (size_t)i * S;
+            if (s[0] >= 0.5 && s[1] >= 0.0) return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
+        }
     }
     int cmax = 0;
     if (carry)
@@ -562,7 +571,7 @@ int azg_search_resident(azg_engine* e) {
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     hipError_t rc;
-    const bool cartpole = e->cfg.env_id == AZG_ENV_CARTPOLE;
+    const bool cartpole = e->cfg.mode == AZG_MODE_DISCRETE;   // the discrete family's kernels (CartPole, MountainCar)
     if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : azg_ls_dispatch_pendulum(e);
     else if (cartpole) rc = azg_dispatch_cartpole(e);
     else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
@@ -612,7 +621,7 @@ static int launch_results(azg_engine* e) {
         if (trc) return trc;
     }
     int B = e->cfg.n_trees;
-    hipLaunchKernelGGL(results_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
+    hipLaunchKernelGGL(results_kernel, dim3((B + RS_TREES - 1) / RS_TREES), dim3(16 * RS_TREES), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
                        e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
     HIPCHK(e, hipGetLastError());
     e->results_valid = 1;   // (in stream order: whatever reads the buffers is ordered after this launch)
@@ -754,7 +763,7 @@ int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // head, waves, tree groups -- see search_kernel.cuh / team.cuh); returns the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
-    const int env = e->cfg.env_id == AZG_ENV_CARTPOLE ? 0 : 2;   // (both Pendulum versions run the ENV = 2 instantiation)
+    const int env = e->cfg.mode == AZG_MODE_DISCRETE ? 0 : 2;   // (ENV = 0: the discrete family, ENV = 2: both Pendulum versions)
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
     int w = 0;
     switch (e->kernel_form) {
@@ -785,7 +794,7 @@ int azg_obs_dim(const azg_engine* e) { return e ? e->S_obs : AZG_E_INVALID; }
 int azg_synthetic_roots(azg_engine* e, double* roots) {
     if (!e || !roots) return AZG_E_INVALID;
     for (int i = 0; i < e->cfg.n_trees; ++i)
-        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, roots + (size_t)i * e->S_env);
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, azg_reset_kind(e->cfg.env_id), roots + (size_t)i * e->S_env);
     return AZG_OK;
 }
 

@@ -1,4 +1,4 @@
-// env.cuh -- closed-form CartPole / Pendulum dynamics on the device (float64; operation order = alphazero_gym_amd/envs.py).
+// env.cuh -- closed-form CartPole / MountainCar / Pendulum dynamics on the device (float64; operation order = alphazero_gym_amd/envs.py).
 #pragma once
 #include "records.h"
 
@@ -38,6 +38,30 @@ __device__ __forceinline__ void cartpole_step(const double* s, int action, doubl
     o[0] = x; o[1] = x_dot; o[2] = theta; o[3] = theta_dot;
     *done = (x < -x_thr) || (x > x_thr) || (theta < -theta_thr) || (theta > theta_thr);
     *reward = 1.0;
+}
+
+// gym MountainCarEnv.step (MountainCar-v0; three actions); same operation order as oracle/azg_oracle.c mountaincar_step.
+// The state uses slots 0..1 of the discrete family's 4-slot state vector (slots 2..3 stay zero, and so do observations 2..3).
+__device__ __forceinline__ void mountaincar_step(const double* s, int action, double* o, double* reward, int* done) {
+    const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5, goal_velocity = 0.0;
+    const double force = 0.001, gravity = 0.0025;
+    double position = s[0], velocity = s[1];
+    double sn, cs;
+    azg_sincos(3.0 * position, &sn, &cs);
+    velocity = velocity + ((double)(action - 1) * force + cs * (-gravity));
+    velocity = velocity < -max_speed ? -max_speed : (velocity > max_speed ? max_speed : velocity);
+    position = position + velocity;
+    position = position < min_position ? min_position : (position > max_position ? max_position : position);
+    if (position == min_position && velocity < 0.0) velocity = 0.0;
+    o[0] = position; o[1] = velocity; o[2] = 0.0; o[3] = 0.0;
+    *done = (position >= goal_position) && (velocity >= goal_velocity);
+    *reward = -1.0;
+}
+
+// one step of the discrete family's environment (the kernels are instantiated once per family: ENV = AZG_ENV_CARTPOLE)
+__device__ __forceinline__ void discrete_env_step(int env_id, const double* s, int action, double* o, double* reward, int* done) {
+    if (env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(s, action, o, reward, done);
+    else cartpole_step(s, action, o, reward, done);
 }
 
 // gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node

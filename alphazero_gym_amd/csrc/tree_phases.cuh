@@ -52,7 +52,7 @@ template <bool CONT> __device__ __forceinline__ void set_best(RecL* r, const Rec
 // all 16 lanes of the tree.  pick >= 0: that child index instead of the arg-max (epsilon-greedy).
 template <int ENV, int TLDS, typename Rec>
 __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TLDS>& ts, int p, const Rec& hp, int sub, const double* s_sqrt,
-                                            int pick) {
+                                            int pick, unsigned gtree = 0u) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     const int K = hp.n_child;
     // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
@@ -80,6 +80,20 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
         if (pick >= 0) win_c = __shfl(c, pick, 16);
         else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
         else win_c = argmax16_payload(U, valid, sub, c);
+        if (P.tie_random && pick < 0) {
+            // helpers.argmax (helpers.py:46-52): uniform among the children that hold the maximum.  The draw is keyed by the node
+            // and its visit count: between two visits of a node nothing its scores depend on changes.
+            const double m = rowmax16(U, valid);
+            const unsigned row = (unsigned)(__ballot(valid && U == m) >> (threadIdx.x & 48)) & 0xffffu;
+            const int cnt = __popc(row);
+            if (cnt > 1) {
+                const azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, ((unsigned)hp.node_n << 16) ^ (unsigned)p, AZG_STREAM_TIE);
+                int kth = (int)(b.v[0] % (unsigned)cnt);
+                unsigned r2 = row;
+                while (kth-- > 0) r2 &= r2 - 1;                // drop the kth lowest tied lanes
+                win_c = __shfl(c, __builtin_ctz(r2), 16);
+            }
+        }
     } else {
         double win_u = 0.0;
         bool have = false;
@@ -158,7 +172,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
     if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
         double rs[S], sn;
 #pragma unroll
-        for (int k = 0; k < S; ++k) rs[k] = live ? P.roots[(size_t)tree * S + k] : 0.0;
+        for (int k = 0; k < S; ++k) rs[k] = (live && k < P.S) ? P.roots[(size_t)tree * P.S + k] : 0.0;   // (P.S: the env's own state width)
         float obs[4];
         env_obs<ENV>(rs, obs, &sn);
         if (live && sub == 0) {
@@ -263,7 +277,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 ts.hot[st.leaf].n_child = (decltype(ts.hot[st.leaf].n_child))A;
                 ts.hot[st.leaf].first = (decltype(ts.hot[st.leaf].first))k0;
             }
-            if (P.epsilon == 0.0) {
+            if (P.epsilon == 0.0 && !P.tie_random) {
                 // the new node's own selection (refresh_best): its edges all start at Q = V with no visits, so its scores
                 // are V + (prior_a * c_uct as float32) * (sqrt(n + 1) / 1) -- a division by one is exact
                 if (A == 2) {
@@ -286,7 +300,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     }
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
-        const bool keep = !CONT && P.epsilon == 0.0;   // (cached selections: discrete mode, see rec_best)
+        const bool keep = !CONT && P.epsilon == 0.0 && !P.tie_random;   // (cached selections: discrete mode, see rec_best)
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
                                 [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); });
         if constexpr (!CONT) {
@@ -337,7 +351,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     int p = 0;
     bool resumed = false;
     if constexpr (RESUME && !CONT) {
-        if (P.epsilon == 0.0 && P.A == 2 && st.resume > 0) {
+        if (P.epsilon == 0.0 && !P.tie_random && P.A == 2 && st.resume > 0) {
             // same path as a descent from the root down to depth `resume` (tree_phase_a): go on from that node
             resumed = true;
             p = __shfl(st.pid, st.resume, 16);
@@ -365,14 +379,14 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
             if (widen) break;
         }
-        if (CONT || P.epsilon != 0.0) {
-            // scored on the way down (continuous mode; epsilon-greedy selection, MCTS.epsilon_greedy mcts.py:190-195)
+        if (CONT || P.epsilon != 0.0 || P.tie_random) {
+            // scored on the way down (continuous mode; epsilon-greedy selection, MCTS.epsilon_greedy mcts.py:190-195; random ties)
             int pick = -1;
             if (P.epsilon != 0.0) {
                 azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
                 if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
             }
-            chosen = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, pick);
+            chosen = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, pick, gtree);
         } else {
             chosen = rec_best<CONT>(hp);   // taken when the node's statistics last changed (refresh_best)
         }
@@ -454,7 +468,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                     cp.s[0] = sp[0]; cp.s[1] = sp[1]; cp.s[2] = sp[2]; cp.s[3] = sp[3];
                 }
             }
-            cartpole_step(cp.s, chosen - (int)hp.first, ns, &r, &done);
+            discrete_env_step(P.env_id, cp.s, chosen - (int)hp.first, ns, &r, &done);
         }
         float obs[4];
         env_obs<ENV>(ns, obs, &sn);

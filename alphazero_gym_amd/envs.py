@@ -2,7 +2,7 @@
 
 The reference gets its environments from the third-party ``gym`` package (``rl/make_game.py:49-68``,
 ``gym==0.19.0`` in requirements.txt:10), which is neither vendored in the reference nor installed here.
-These classes restate the published CartPole / Pendulum dynamics with the gym 0.19 ``Env`` call
+These classes restate the published CartPole / MountainCar / Pendulum dynamics with the gym 0.19 ``Env`` call
 surface the reference's MCTS uses: ``copy.deepcopy(Env)`` + ``Env.step(action)`` returning
 ``(obs, reward, done, info)`` (alphazero/search/mcts.py:443-449, 680-687), ``Env.reset()``, ``Env.seed()``.
 
@@ -18,6 +18,7 @@ import numpy as np
 ENV_CARTPOLE = 0
 ENV_PENDULUM_V0 = 1
 ENV_PENDULUM_V1 = 2
+ENV_MOUNTAINCAR = 3
 
 
 class _Box:
@@ -101,6 +102,45 @@ class CartPoleEnv(_EnvBase):
         return np.array(self.state, dtype=np.float32), 1.0, done, {}
 
 
+class MountainCarEnv(_EnvBase):
+    """gym ``MountainCar-v0`` (three discrete actions: push left, no push, push right); TimeLimit stripped like CartPole's.
+    The arithmetic is gym 0.19's ``MountainCarEnv.step`` on python floats: ``velocity += (action - 1) * force +
+    cos(3 * position) * (-gravity)``, clip, ``position += velocity``, clip, inelastic left wall, reward -1.0."""
+
+    azg_env_id = ENV_MOUNTAINCAR
+    min_position = -1.2
+    max_position = 0.6
+    max_speed = 0.07
+    goal_position = 0.5
+    goal_velocity = 0.0
+    force = 0.001
+    gravity = 0.0025
+
+    def __init__(self, state=None):
+        low = np.array([self.min_position, -self.max_speed], dtype=np.float32)
+        high = np.array([self.max_position, self.max_speed], dtype=np.float32)
+        self.observation_space = _Box(low, high, (2,))
+        self.action_space = _Discrete(3)
+        self.seed(None)
+        self.state = None if state is None else tuple(float(v) for v in state)
+
+    def reset(self):
+        self.state = (float(self.np_random.uniform(low=-0.6, high=-0.4)), 0.0)
+        return np.array(self.state, dtype=np.float32)
+
+    def step(self, action):
+        position, velocity = self.state
+        velocity = velocity + ((int(action) - 1) * self.force + math.cos(3 * position) * (-self.gravity))
+        velocity = min(max(velocity, -self.max_speed), self.max_speed)
+        position = position + velocity
+        position = min(max(position, self.min_position), self.max_position)
+        if position == self.min_position and velocity < 0:
+            velocity = 0.0
+        done = bool(position >= self.goal_position and velocity >= self.goal_velocity)
+        self.state = (position, velocity)
+        return np.array(self.state, dtype=np.float32), -1.0, done, {}
+
+
 class PendulumEnv(_EnvBase):
     """gym ``Pendulum-v0`` (``version=0``: speed clipped after integrating theta) / ``Pendulum-v1`` (clipped before)."""
 
@@ -156,7 +196,9 @@ def make_game(game: str):
         return CartPoleEnv()
     if name == "pendulum":
         return PendulumEnv(version=0 if game.endswith("v0") else 1)
-    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole and Pendulum only")
+    if name == "mountaincar":
+        return MountainCarEnv()
+    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole, MountainCar and Pendulum only")
 
 
 class VecPendulum:

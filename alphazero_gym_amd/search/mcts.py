@@ -26,11 +26,13 @@ def env_signature(env) -> Tuple[int, np.ndarray]:
     name = type(u).__name__
     if name == "CartPoleEnv":
         return _capi.ENV_CARTPOLE, np.asarray(u.state, dtype=np.float64)
+    if name == "MountainCarEnv":
+        return _capi.ENV_MOUNTAINCAR, np.asarray(u.state, dtype=np.float64)
     if name == "PendulumEnv":
         spec = getattr(getattr(u, "spec", None), "id", "") or ""
         return (_capi.ENV_PENDULUM_V0 if spec.endswith("v0") else _capi.ENV_PENDULUM_V1), np.asarray(u.state, dtype=np.float64)
     raise NotImplementedError(
-        f"{name}: the engine steps CartPole and Pendulum in closed form on the GPU; other environments are not supported")
+        f"{name}: the engine steps CartPole, MountainCar and Pendulum in closed form on the GPU; other environments are not supported")
 
 
 def _weights_version(model) -> Tuple:

@@ -232,24 +232,33 @@ AZG_HD float azg_u01(uint32_t x) {
 #define AZG_STREAM_PW 0u      /* progressive-widening action noise, N(0,1) */
 #define AZG_STREAM_EPS 1u     /* epsilon-greedy: v[0] -> u, v[1] -> random child */
 #define AZG_STREAM_ROOT 2u    /* synthetic root states (bench / self-play resets): counter (tree, episode, 0, stream) */
+#define AZG_STREAM_TIE 4u     /* AZG_TIE_RANDOM: v[0] picks among tied children: counter (tree, search, node_n << 16 ^ node record, stream) */
 #define AZG_STREAM_ACT 3u     /* self-play: final action sampled from the visit counts: counter (tree, step, 0, stream) */
 
 /* fixed-seed reset state of game `tree`, episode `episode` (Pendulum theta~U(-pi,pi), theta_dot~U(-1,1);
- * CartPole ~U(-0.05,0.05)^4); env 0 = CartPole, else Pendulum */
-AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s);
+ * CartPole ~U(-0.05,0.05)^4; MountainCar position~U(-0.6,-0.4), velocity 0: the envs' own reset laws).
+ * kind: AZG_RESET_PENDULUM / AZG_RESET_CARTPOLE / AZG_RESET_MOUNTAINCAR (azg_reset_kind(env_id)) */
+#define AZG_RESET_PENDULUM 0
+#define AZG_RESET_CARTPOLE 1
+#define AZG_RESET_MOUNTAINCAR 2
+AZG_HD int azg_reset_kind(int env_id) { return env_id == 0 ? AZG_RESET_CARTPOLE : (env_id == 3 ? AZG_RESET_MOUNTAINCAR : AZG_RESET_PENDULUM); }
+AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int kind, double* s);
 
 /* the engine's draw #`draw` of stream `stream` for (global tree id, search index) */
 AZG_HD azg_u32x4 azg_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, uint32_t stream) {
     return azg_philox4x32(tree, search, draw, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s) {
+AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int kind, double* s) {
     const double pi = 3.141592653589793;
     azg_u32x4 b = azg_draw(seed, tree, episode, 0u, AZG_STREAM_ROOT);
     double u[4];
     for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
-    if (env_is_cartpole) {
+    if (kind == AZG_RESET_CARTPOLE) {
         for (int k = 0; k < 4; ++k) s[k] = -0.05 + 0.1 * u[k];
+    } else if (kind == AZG_RESET_MOUNTAINCAR) {
+        s[0] = -0.6 + 0.2 * u[0];
+        s[1] = 0.0;
     } else {
         s[0] = -pi + 2.0 * pi * u[0];
         s[1] = -1.0 + 2.0 * u[1];

@@ -30,7 +30,7 @@ extern "C" {
 enum { AZG_OK = 0, AZG_E_INVALID = -1, AZG_E_TERMINAL_ROOT = -2, AZG_E_DEVICE = -3, AZG_E_STATE = -4, AZG_E_UNSUPPORTED = -5 };
 
 /* closed-form environments (gym classic control; call sites alphazero/search/mcts.py:443-449, 680-687) */
-enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2 };
+enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2, AZG_ENV_MOUNTAINCAR = 3 };
 /* MCTSDiscrete (mcts.py:310-526) / MCTSContinuous (mcts.py:529-741) */
 enum { AZG_MODE_DISCRETE = 0, AZG_MODE_CONTINUOUS = 1 };
 /* V_target_policy (mcts.py:299-304) */
@@ -39,6 +39,11 @@ enum { AZG_VT_OFF_POLICY = 0, AZG_VT_ON_POLICY = 1, AZG_VT_GREEDY = 2 };
 enum { AZG_ACT_RELU = 0, AZG_ACT_ELU = 1, AZG_ACT_LEAKYRELU = 2, AZG_ACT_RELU6 = 3, AZG_ACT_SILU = 4, AZG_ACT_HARDSWISH = 5 };
 
 #define AZG_MAX_HIDDEN_LAYERS 8
+/* Ties in selectionUCT's arg-max.  The reference picks one of the tied children with random.choice (helpers.py:46-52), which
+ * no fixed-seed comparison can follow; AZG_TIE_FIRST (default, the parity setting: the goldens assert that no tie occurred)
+ * takes the lowest index, AZG_TIE_RANDOM picks uniformly among the tied children with a Philox draw keyed by (tree, search,
+ * node record, node visit count) -- the reference's distribution, reproducible, same on the CPU oracle and the GPU. */
+enum { AZG_TIE_FIRST = 0, AZG_TIE_RANDOM = 1 };
 
 /* Constructor kwargs of MCTSDiscrete.__init__ (mcts.py:316-362) / MCTSContinuous.__init__ (mcts.py:537-587),
  * plus the batch geometry. */
@@ -52,7 +57,7 @@ typedef struct azg_config {
     int32_t num_actions;   /* discrete only */
     int32_t v_target;      /* AZG_VT_* */
     int32_t tree_id_base;  /* global id of local tree 0 (multi-GPU sharding; keys the RNG streams) */
-    int32_t reserved0;
+    int32_t tie_break;     /* AZG_TIE_* : what helpers.argmax (helpers.py:30-52) does with exactly equal scores */
     double c_uct;
     double gamma;
     double epsilon;

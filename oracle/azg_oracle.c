@@ -123,11 +123,15 @@ const char* azo_last_error(const azg_engine* e) { return e ? e->err : g_create_e
 /* ------------------------------------------------------------------ environments (float64) */
 
 static int env_state_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : 2; }
-static int env_obs_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : 3; }
+static int env_obs_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : (env == AZG_ENV_MOUNTAINCAR ? 2 : 3); }
+static int env_is_discrete(int env) { return env == AZG_ENV_CARTPOLE || env == AZG_ENV_MOUNTAINCAR; }
+static int env_num_actions(int env) { return env == AZG_ENV_CARTPOLE ? 2 : (env == AZG_ENV_MOUNTAINCAR ? 3 : 0); }
 
 static void env_obs(int env, const double* s, float* obs) {
     if (env == AZG_ENV_CARTPOLE) {
         for (int i = 0; i < 4; ++i) obs[i] = (float)s[i];
+    } else if (env == AZG_ENV_MOUNTAINCAR) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1];
     } else {
         double sn, cs;
         azg_sincos(s[0], &sn, &cs);
@@ -157,6 +161,24 @@ static void cartpole_step(const double* s, int action, double* o, double* reward
     *reward = 1.0;
 }
 
+/* gym MountainCarEnv.step (MountainCar-v0: three actions, push left / none / right): velocity += (a - 1) * force + cos(3 x) * (-gravity),
+ * clipped to +-max_speed; x += velocity, clipped to [-1.2, 0.6]; an inelastic wall on the left; reward -1 per step; done at the flag */
+static void mountaincar_step(const double* s, int action, double* o, double* reward, int* done) {
+    const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.5, goal_velocity = 0.0;
+    const double force = 0.001, gravity = 0.0025;
+    double position = s[0], velocity = s[1];
+    double sn, cs;
+    azg_sincos(3.0 * position, &sn, &cs);
+    velocity = velocity + ((double)(action - 1) * force + cs * (-gravity));
+    velocity = velocity < -max_speed ? -max_speed : (velocity > max_speed ? max_speed : velocity);
+    position = position + velocity;
+    position = position < min_position ? min_position : (position > max_position ? max_position : position);
+    if (position == min_position && velocity < 0.0) velocity = 0.0;
+    o[0] = position; o[1] = velocity;
+    *done = (position >= goal_position) && (velocity >= goal_velocity);
+    *reward = -1.0;
+}
+
 /* gym PendulumEnv.step (v0: clip after integrating theta; v1: clip before); the float32 action is widened to float64 */
 static void pendulum_step(int v1, const double* s, float action, double* o, double* reward, int* done) {
     const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
@@ -184,6 +206,7 @@ static void pendulum_step(int v1, const double* s, float action, double* o, doub
 }
 
 static int env_root_terminal(int env, const double* s) {
+    if (env == AZG_ENV_MOUNTAINCAR) return s[0] >= 0.5 && s[1] >= 0.0;
     if (env != AZG_ENV_CARTPOLE) return 0;
     const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
     return (s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr);
@@ -344,13 +367,14 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(NULL, AZG_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(NULL, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(NULL, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > 2) return fail(NULL, AZG_E_INVALID, "unknown env_id");
-    if (cfg->mode == AZG_MODE_DISCRETE && cfg->env_id != AZG_ENV_CARTPOLE)
+    if (cfg->env_id < 0 || cfg->env_id > 3) return fail(NULL, AZG_E_INVALID, "unknown env_id");
+    if (cfg->mode == AZG_MODE_DISCRETE && !env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole)");
-    if (cfg->mode == AZG_MODE_CONTINUOUS && cfg->env_id == AZG_ENV_CARTPOLE)
+    if (cfg->mode == AZG_MODE_CONTINUOUS && env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
-    if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != 2)
-        return fail(NULL, AZG_E_INVALID, "CartPole has num_actions == 2");
+    if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(NULL, AZG_E_INVALID, "unknown tie_break");
+    if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != env_num_actions(cfg->env_id))
+        return fail(NULL, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3)");
     azg_engine* e = (azg_engine*)calloc(1, sizeof(azg_engine));
     e->cfg = *cfg;
     e->S_env = env_state_dim(cfg->env_id);
@@ -548,6 +572,7 @@ static int select_child(ctx_t* c, int p) {
     double sq = sqrt((double)(t->node_n[p] + 1));
     int best = -1;
     double bestU = 0.0;
+    double Us[64];
     float cf = (float)e->cfg.c_uct;
     for (int i = 0; i < K; ++i) {
         int k = t->child[(size_t)p * e->Kmax + i];
@@ -561,6 +586,19 @@ static int select_child(ctx_t* c, int p) {
             U = t->edge_Q[k] + e->cfg.c_uct * ratio;
         }
         if (best < 0 || U > bestU) { best = k; bestU = U; }
+        Us[i < 64 ? i : 63] = U;
+    }
+    if (e->cfg.tie_break == AZG_TIE_RANDOM && K <= 64) {
+        /* helpers.argmax (helpers.py:46-52): uniform among the children that hold the maximum; the draw is keyed by the node and
+         * its visit count, so it does not matter when between two visits of the node the selection is taken */
+        int cnt = 0;
+        for (int i = 0; i < K; ++i) cnt += (Us[i] == bestU);
+        if (cnt > 1) {
+            azg_u32x4 b = azg_draw(e->cfg.seed, c->gtree, c->search, ((uint32_t)t->node_n[p] << 16) ^ (uint32_t)p, AZG_STREAM_TIE);
+            int kth = (int)(b.v[0] % (uint32_t)cnt);
+            for (int i = 0; i < K; ++i)
+                if (Us[i] == bestU && kth-- == 0) { best = t->child[(size_t)p * e->Kmax + i]; break; }
+        }
     }
     return best;
 }
@@ -609,6 +647,7 @@ static void search_tree(ctx_t* c, const double* root, int carry) {
             int done;
             const double* s = t->state + (size_t)node * e->S_env;
             if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(s, (int)t->edge_action[k], ns, &r, &done);
+            else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(s, (int)t->edge_action[k], ns, &r, &done);
             else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, s, t->edge_action[k], ns, &r, &done);
             if (e->cfg.mode == AZG_MODE_CONTINUOUS) r = r / e->cfg.reward_scale;   /* mcts.py:687 */
             make_node(c, k, ns, r, done);
@@ -750,7 +789,7 @@ int azo_obs_dim(const azg_engine* e) { return e ? e->S_obs : AZG_E_INVALID; }
 int azo_synthetic_roots(azg_engine* e, double* roots) {
     if (!e || !roots) return AZG_E_INVALID;
     for (int i = 0; i < e->cfg.n_trees; ++i)
-        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, roots + (size_t)i * e->S_env);
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, azg_reset_kind(e->cfg.env_id), roots + (size_t)i * e->S_env);
     return AZG_OK;
 }
 
@@ -779,7 +818,7 @@ int azo_selfplay_begin_ex(azg_engine* e, const azg_selfplay_config* c) {
     e->sp_temperature = c->temperature; e->sp_agent_eps = c->agent_epsilon;
     e->sp_step_idx = 0;
     for (int i = 0; i < B; ++i)
-        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, e->cfg.env_id == AZG_ENV_CARTPOLE, e->roots + (size_t)i * e->S_env);
+        azg_reset_state(e->cfg.seed, (uint32_t)(e->cfg.tree_id_base + i), 0u, azg_reset_kind(e->cfg.env_id), e->roots + (size_t)i * e->S_env);
     memset(e->carry, 0, 4 * (size_t)B);
     return AZG_OK;
 }
@@ -881,6 +920,7 @@ int azo_selfplay_step(azg_engine* e) {
         double ns[4], r;
         int done;
         if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(root, pick, ns, &r, &done);
+        else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(root, pick, ns, &r, &done);
         else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, root, t->edge_action[krec], ns, &r, &done);
         e->sp_ret[i] = e->sp_ret[i] + r;
         e->sp_t[i] += 1;
@@ -890,7 +930,7 @@ int azo_selfplay_step(azg_engine* e) {
             e->sp_ret[i] = 0.0;
             e->sp_t[i] = 0;
             e->sp_episode[i] += 1;
-            azg_reset_state(e->cfg.seed, gtree, (uint32_t)e->sp_episode[i], e->cfg.env_id == AZG_ENV_CARTPOLE, root);
+            azg_reset_state(e->cfg.seed, gtree, (uint32_t)e->sp_episode[i], azg_reset_kind(e->cfg.env_id), root);
             e->carry[i] = 0;
         } else {
             memcpy(root, ns, sizeof(double) * S);
@@ -993,8 +1033,8 @@ void azo_eps_draw(uint64_t seed, uint32_t tree, uint32_t search, uint32_t draw, 
 
 /* the self-play draws: a game's reset state of an episode, and the final-action draw of a step (u01 float for
  * `random.random() < epsilon`, the double uniform of the inverse-CDF sample, the raw word of the uniform index) */
-void azo_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int env_is_cartpole, double* s) {
-    azg_reset_state(seed, tree, episode, env_is_cartpole, s);
+void azo_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int kind, double* s) {
+    azg_reset_state(seed, tree, episode, kind, s);
 }
 
 void azo_act_draw(uint64_t seed, uint32_t tree, uint32_t step, float* u01, double* u, uint32_t* word1) {
@@ -1029,6 +1069,7 @@ int azo_mlp_eval(azg_engine* e, const float* obs, size_t n, float* value, float*
 int azo_env_step(int env_id, const double* state, float action, double* next, double* reward, int32_t* done, float* obs) {
     int d = 0;
     if (env_id == AZG_ENV_CARTPOLE) cartpole_step(state, (int)action, next, reward, &d);
+    else if (env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(state, (int)action, next, reward, &d);
     else if (env_id == AZG_ENV_PENDULUM_V0 || env_id == AZG_ENV_PENDULUM_V1) pendulum_step(env_id == AZG_ENV_PENDULUM_V1, state, action, next, reward, &d);
     else return AZG_E_INVALID;
     *done = d;

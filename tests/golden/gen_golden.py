@@ -3,6 +3,7 @@
 
     python tests/golden/gen_golden.py            # needs /root/reference; writes tests/golden/*.npz
     python tests/golden/gen_golden.py t7         # only the self-play tier
+    python tests/golden/gen_golden.py t1 NAME... # only the named T1 cases
     python tests/golden/gen_golden.py wide       # only t2_mlp_wide.npz (4x1024, 2x512), t3_full_rollouts.npz (n_rollouts = 200), t5_update.npz
 
 The reference (timoklein/alphazero-gym) is imported unmodified from /root/reference.  `gym`, `hydra`
@@ -72,7 +73,7 @@ from alphazero.network.policies import make_policy  # noqa: E402
 
 import oracle_lib as O  # noqa: E402
 from alphazero_gym_amd import _capi  # noqa: E402
-from alphazero_gym_amd.envs import CartPoleEnv, PendulumEnv  # noqa: E402
+from alphazero_gym_amd.envs import CartPoleEnv, MountainCarEnv, PendulumEnv  # noqa: E402
 
 torch.set_num_threads(1)
 TIES = {"n": 0}
@@ -196,7 +197,7 @@ def dump_reference_tree(root, R):
 def run_t1(case):
     """One T1 case: several independent trees, one reference MCTS object per tree."""
     cont = case["mode"] == 1
-    in_dim = 3 if cont else 4
+    in_dim = 3 if cont else (2 if case["env_id"] == 3 else 4)
     n_dist = 2 if cont else case["num_actions"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
                          gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0),
@@ -215,7 +216,7 @@ def run_t1(case):
             env = PendulumEnv(state=root, version=1 if case["env_id"] == 2 else 0)
             root_obs = env._get_obs()
         else:
-            env = CartPoleEnv(state=root)
+            env = MountainCarEnv(state=root) if case["env_id"] == 3 else CartPoleEnv(state=root)
             root_obs = np.array(env.state, dtype=np.float32)
         mcts = None
         carry = 0
@@ -291,6 +292,14 @@ T1_CASES = {
     "t1_cartpole_reuse": dict(env_id=0, mode=0, num_actions=2, n_sims=25, c_uct=1.5, gamma=1, epsilon=0.0,
                               v_target="off_policy", hidden=[128, 128], act="relu", wseed=34, seed=34, reuse_steps=4,
                               roots=[[0.03, 0.01, -0.02, 0.04], [-0.01, 0.02, 0.04, -0.03]]),
+    # three actions (mcts.py:316-327 num_actions, 412-415): gym MountainCar-v0; roots in the valley, next to the flag (terminal
+    # children), at the left wall and on the slope
+    "t1_mountaincar_default": dict(env_id=3, mode=0, num_actions=3, n_sims=90, c_uct=0.8, gamma=0.99, epsilon=0.0,
+                                   v_target="off_policy", hidden=[64, 64], act="relu", wseed=17, seed=21, wscale=2.0,
+                                   roots=[[-0.5, 0.0], [0.43, 0.035], [-1.19, -0.03], [0.3, 0.05]]),
+    "t1_mountaincar_epsgreedy_reuse": dict(env_id=3, mode=0, num_actions=3, n_sims=40, c_uct=2.0, gamma=1, epsilon=0.15,
+                                           v_target="on_policy", hidden=[128, 128], act="elu", wseed=19, seed=22, wscale=3.0,
+                                           reuse_steps=3, roots=[[-0.45, 0.01], [0.41, 0.04]]),
 }
 
 
@@ -939,6 +948,14 @@ def main_t7():
 def main():
     if sys.argv[1:] == ["t7"]:   # only the self-play tier (the other fixtures are left untouched)
         return main_t7()
+    if sys.argv[1:2] == ["t1"]:   # only the named T1 cases: python gen_golden.py t1 t1_mountaincar_default ...
+        for name in sys.argv[2:]:
+            TIES["n"] = 0
+            res = run_t1(T1_CASES[name])
+            assert TIES["n"] == 0, f"{name}: argmax tie occurred in the reference run; pick other inputs"
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+            print(name, "records", res["n_records"].tolist(), "counts", res["counts"].tolist())
+        return
     if sys.argv[1:] == ["wide"]:   # only the wide-network T2 cases and the n_rollouts = 200 T3 legs
         return main_wide()
     for name, case in T1_CASES.items():

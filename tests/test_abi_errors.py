@@ -31,6 +31,18 @@ def test_create_rejects_bad_configs(engine_cls):
     assert ei.value.code == _capi.AZG_E_INVALID
     with pytest.raises(_capi.EngineError):
         engine_cls(env_id=7, mode=1, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0)
+    for env_id, bad in ((0, 3), (3, 2), (3, 4)):                                                    # num_actions is the env's: CartPole 2, MountainCar 3
+        with pytest.raises(_capi.EngineError) as ei:
+            engine_cls(env_id=env_id, mode=0, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0, num_actions=bad)
+        assert ei.value.code == _capi.AZG_E_INVALID
+    with pytest.raises(_capi.EngineError) as ei:
+        engine_cls(env_id=3, mode=1, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0)                     # continuous MCTS on MountainCar
+    assert ei.value.code == _capi.AZG_E_UNSUPPORTED
+    e = engine_cls(env_id=3, mode=0, n_trees=2, n_sims=4, c_uct=1.0, gamma=1.0, num_actions=3)
+    e.set_weights(_capi.make_desc(2, [64], 3, "relu"), O.make_weights(1, 2, [64], 3))
+    with pytest.raises(ValueError):
+        e.search(np.array([[-0.5, 0.0], [0.55, 0.01]]))                                             # a root at the flag is terminal
+    e.close()
 
 
 def test_search_needs_weights_and_results_need_a_search(engine_cls):

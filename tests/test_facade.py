@@ -17,7 +17,7 @@ from alphazero_gym_amd import _capi, config
 from alphazero_gym_amd.agent.agents import ContinuousAgent, DiscreteAgent
 from alphazero_gym_amd.agent.buffers import ReplayBuffer
 from alphazero_gym_amd.agent.losses import A0CLoss, A0CLossTuned, AlphaZeroLoss
-from alphazero_gym_amd.envs import CartPoleEnv, PendulumEnv
+from alphazero_gym_amd.envs import CartPoleEnv, MountainCarEnv, PendulumEnv
 from alphazero_gym_amd.helpers import argmax, stable_normalizer
 from alphazero_gym_amd.network.policies import make_policy
 from alphazero_gym_amd.search.mcts import MCTSContinuous, MCTSDiscrete
@@ -135,6 +135,28 @@ def test_terminal_root_is_a_value_error(backend):
                      root_state=None)
     with pytest.raises(ValueError):
         m.search(CartPoleEnv(state=[3.0, 0, 0, 0]))
+
+
+def test_three_action_env_through_the_facade(backend):
+    """MCTSDiscrete(num_actions=3) (mcts.py:316-327) on gym's MountainCar-v0 restatement: search, return_results shapes for three
+    actions, tree reuse through forward()."""
+    torch.manual_seed(2)
+    pol = make_policy(representation_dim=2, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=3)
+    m = MCTSDiscrete(model=pol, num_actions=3, n_rollouts=30, c_uct=1.5, gamma=0.99, epsilon=0.0, V_target_policy="off_policy", device="cpu",
+                     root_state=None)
+    env = MountainCarEnv(state=[-0.5, 0.0])
+    m.search(env)
+    state, actions, counts, Q, V = m.return_results("max_visit")
+    assert list(actions) == [0, 1, 2] and counts.sum() == 30 and Q.shape == (3,) and state.shape == (2,)
+    a = int(counts.argmax())
+    obs, r, done, _ = env.step(a)
+    m.forward(a, obs)
+    assert m.root_node is not None and m.root_node.n == counts[a] - 1 or m.root_node is None
+    m.search(env)
+    assert m.return_results("max_visit")[2].sum() == 30
+    with pytest.raises(ValueError):
+        m.root_node = None
+        m.search(MountainCarEnv(state=[0.52, 0.01]))
 
 
 def test_batched_search_over_a_list_of_envs(backend):

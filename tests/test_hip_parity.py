@@ -127,6 +127,13 @@ CONFIGS = [
     # up to 16 children per node: the LDS child-list pool grows through all its block sizes (4, 8, 16)
     (2, 1, [256, 256], "relu", 120, dict(c_uct=0.2, gamma=0.98, c_pw=1.4, kappa=0.5)),
     (1, 1, [64, 64], "elu", 254, dict(c_uct=0.02, gamma=1.0, c_pw=1.0, kappa=0.5)),
+    # three actions (gym MountainCar-v0): the generic-A paths of evaluation, selection, re-scoring; LDS trees of 8- and 9-bit ids,
+    # global trees, a 2x256 network (8-wave variants), a wide one (lock-step path), epsilon-greedy
+    (3, 0, [64, 64], "relu", 60, dict(c_uct=0.8, gamma=0.99, num_actions=3)),
+    (3, 0, [128, 128], "elu", 120, dict(c_uct=2.0, gamma=1.0, num_actions=3, epsilon=0.2, v_target="on_policy")),
+    (3, 0, [256, 256], "relu", 50, dict(c_uct=1.5, gamma=0.97, num_actions=3)),
+    (3, 0, [512, 512], "relu", 25, dict(c_uct=1.5, gamma=1.0, num_actions=3)),
+    (3, 0, [64], "relu", 200, dict(c_uct=3.0, gamma=0.98, num_actions=3, v_target="greedy")),
 ]
 
 
@@ -159,7 +166,7 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
             monkeypatch.setenv("AZG_LS_TEAM", "0")            # the per-layer launches instead of the persistent team kernel
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
-    in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else (4, 2)
+    in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else ((2, 3) if env == 3 else (4, 2))
     desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
     blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
     if ln:
@@ -167,9 +174,12 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     o = O.OracleEngine(**kw)
     roots = o.synthetic_roots()
     o.close()
-    if mode == 0:
+    if env == 0:
         roots[3] = [2.35, 1.5, 0.0, 0.0]      # terminates quickly
         roots[5] = [0.0, 0.0, 0.2, 1.0]
+    if env == 3:
+        roots[3] = [0.44, 0.04]               # the flag is two steps away
+        roots[5] = [-1.195, -0.05]            # into the left wall
     carry = (np.arange(B) % 7).astype(np.int32) if mode == 0 else None
     forms = []
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3, forms=forms)
@@ -578,3 +588,37 @@ def test_results_resident_hands_out_the_same_numbers_without_a_copy(native):
     for k in want:
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=k)
     e.close()
+
+
+TIE_CASES = [
+    dict(env_id=0, mode=0, n_sims=60, c_uct=1.5, gamma=1.0, num_actions=2),
+    dict(env_id=3, mode=0, n_sims=80, c_uct=1.0, gamma=1.0, num_actions=3),
+    dict(env_id=3, mode=0, n_sims=50, c_uct=1.0, gamma=0.97, num_actions=3, epsilon=0.2),
+    dict(env_id=2, mode=1, n_sims=60, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5),
+]
+
+
+def _tie_engine(cls, kw, tie, B=21):
+    """A network of zeros: every value is 0 and every prior uniform, so exactly equal selection scores are the rule."""
+    e = cls(n_trees=B, seed=77, tree_id_base=11, tie_break=tie, **kw)
+    cont = kw["mode"] == 1
+    in_dim, n_dist = (3, 2) if cont else ((2, 3) if kw["env_id"] == 3 else (4, 2))
+    e.set_weights(_capi.make_desc(in_dim, [64, 64], n_dist, "relu"), np.zeros_like(O.make_weights(1, in_dim, [64, 64], n_dist)))
+    roots = e.synthetic_roots()
+    e.search(roots)
+    out = (e.results(), e.dump_tree())
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("kw", TIE_CASES, ids=["cartpole", "mountaincar", "mountaincar_eps", "pendulum"])
+def test_random_tie_break_is_the_same_on_the_device_and_the_oracle(native, kw):
+    """AZG_TIE_RANDOM (helpers.py:46-52's random.choice among exactly equal scores, as a Philox-keyed draw): identical trees on
+    the HIP engine and on the oracle, and different from the lowest-index rule wherever ties occur."""
+    a = _tie_engine(native.HipEngine, kw, "random")
+    b = _tie_engine(O.OracleEngine, kw, "random")
+    _assert_same(a, b)
+    first = _tie_engine(native.HipEngine, kw, "first")
+    _assert_same(first, _tie_engine(O.OracleEngine, kw, "first"))
+    if kw["mode"] == 0:
+        assert not np.array_equal(a[0]["counts"], first[0]["counts"])   # (Pendulum's sampled actions make ties rare: no claim there)

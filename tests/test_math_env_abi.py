@@ -7,7 +7,7 @@ import re
 import numpy as np
 
 import oracle_lib as O
-from alphazero_gym_amd.envs import CartPoleEnv, PendulumEnv
+from alphazero_gym_amd.envs import CartPoleEnv, MountainCarEnv, PendulumEnv
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -75,6 +75,32 @@ def test_cartpole_c_env_matches_numpy_env():
         np.testing.assert_array_equal(obsc, obs)
         n_done += done
     assert 0 < n_done < 400
+
+
+def test_mountaincar_c_env_matches_python_env():
+    """gym MountainCar-v0 (three actions): the oracle's step against the Python restatement -- in the valley, at the inelastic left
+    wall, at both speed limits and across the flag (done)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_done = n_wall = 0
+    for i in range(600):
+        s = np.array([rng.uniform(-1.2, 0.6), rng.uniform(-0.07, 0.07)])
+        if i % 7 == 0:
+            s = np.array([rng.uniform(-1.2, -1.19), rng.uniform(-0.07, 0.0)])    # into the wall
+        if i % 11 == 0:
+            s = np.array([rng.uniform(0.44, 0.5), rng.uniform(0.0, 0.07)])       # up to the flag
+        a = int(rng.integers(0, 3))
+        e = MountainCarEnv(state=s)
+        obs, r, done, _ = e.step(a)
+        nxt, rc, dc, obsc = O.env_step(3, s, a)
+        np.testing.assert_allclose(nxt, e.state, rtol=0, atol=1e-15)
+        assert rc == -1.0 == r and dc == done
+        np.testing.assert_array_equal(obsc, obs)
+        n_done += done
+        n_wall += (nxt[0] == -1.2 and nxt[1] == 0.0)
+    assert n_done > 10 and n_wall > 10
+    for ep in range(5):
+        s = O.reset_state(9, 3, ep, False, env_id=3)
+        assert -0.6 <= s[0] <= -0.4 and s[1] == 0.0
 
 
 def test_hip_library_exports_every_symbol_of_the_header():

@@ -75,3 +75,26 @@ def test_full_size_cartpole_invariants_on_gpu():
     check_invariants(V, {k: v[sub] for k, v in res.items()}, {k: v[sub] for k, v in dump.items()}, 100, None, False)
     assert (res["counts"].sum(1) == 100).all()
     e.close()
+
+
+def test_random_tie_break_spreads_over_tied_children():
+    """AZG_TIE_RANDOM on the oracle: with an all-zero network the three MountainCar actions tie at the root of every fresh tree
+    (Q = V = 0, equal priors); lowest-index tie-breaking always starts with action 0, the Philox-keyed uniform pick spreads the
+    first visit over all three (helpers.py:46-52), reproducibly."""
+    import oracle_lib as O
+    from alphazero_gym_amd import _capi
+    kw = dict(env_id=3, mode=0, n_trees=300, n_sims=1, c_uct=1.0, gamma=1.0, num_actions=3, seed=5)
+
+    def first_visit(tie):
+        e = O.OracleEngine(tie_break=tie, **kw)
+        e.set_weights(_capi.make_desc(2, [64], 3, "relu"), np.zeros_like(O.make_weights(1, 2, [64], 3)))
+        e.search(e.synthetic_roots())
+        c = e.results()["counts"]
+        e.close()
+        return c.argmax(1)
+
+    assert (first_visit("first") == 0).all()
+    r1, r2 = first_visit("random"), first_visit("random")
+    np.testing.assert_array_equal(r1, r2)
+    share = np.bincount(r1, minlength=3) / 300.0
+    assert (share > 0.2).all() and (share < 0.47).all(), share
