@@ -248,13 +248,15 @@ struct TileMem {
 };
 
 // One output tile of a hidden->hidden layer: TG tree groups (from g0) x UT unit tiles (slice us), by one 256-thread workgroup.
-template <int HP, bool LAST, int TG, int UT, bool SC1>
+// KC_: k-blocks per staged chunk (LS_KC by default; the team kernel's three- and four-workgroups-per-CU forms use shorter chunks so
+// that their stages fit the CU's LDS side by side).
+template <int HP, bool LAST, int TG, int UT, bool SC1, int KC_ = LS_KC>
 __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab, bool wt = true) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
     constexpr int WPG = 4 / TG;            // waves per tree group
     constexpr int WT = UT / WPG;           // unit tiles per wave
-    constexpr int S4 = HP / 16, NU = HP / (16 * UT), KC = LS_KC, NCHUNK = S4 / KC;
+    constexpr int S4 = HP / 16, NU = HP / (16 * UT), KC = KC_, NCHUNK = S4 / KC;
     static_assert(S4 % KC == 0, "k-blocks per layer must be a multiple of the chunk");
     constexpr int ASZ = UT * KC * 64, BSZ = TG * KC * 64;   // float4 entries of a stage's A [UT tiles][KC][64] and B [TG groups][KC][64]
     constexpr int STAGE = ASZ + BSZ;

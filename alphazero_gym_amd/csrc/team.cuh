@@ -43,7 +43,7 @@
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
-#define LS_TILE_STAGE_F4 (2 * (4 + 2) * LS_KC * 64)   // float4 entries of the tile routine's two stages (TG = 2, UT = 4)
+#define LS_TILE_STAGE_F4(KC) (2 * (4 + 2) * (KC) * 64)   // float4 entries of the tile routine's two stages (TG = 2, UT = 4)
 
 struct TeamCtl {
     unsigned* cnt;         // [teams][TEAM_MAX_CNT][TEAM_CNT_STRIDE]
@@ -57,9 +57,10 @@ __host__ __device__ inline size_t team_tree_bytes(int R, bool cont, int tlds) {
     size_t per = (size_t)R * 16 + (cont ? (size_t)POOL_UNITS(R) * (tlds == TS_LDS9 ? 8 : 4) : (size_t)R * 4);
     return (per + 15) / 16 * 16;
 }
-__host__ __device__ inline size_t team_table_off() { return (size_t)LS_TILE_STAGE_F4 * 16; }
-__host__ __device__ inline size_t team_tree_off(int tab_n, int n_sims) {
-    return (team_table_off() + (size_t)tab_n * 8 + (size_t)(n_sims + 2) * 4 + 15) / 16 * 16;
+// (the stages double as the head partials' landing area between tiles: NCH * 64 float4, at most 16 * 64)
+__host__ __device__ inline size_t team_table_off(int kc) { size_t f4 = LS_TILE_STAGE_F4(kc); return (f4 < 1024 ? 1024 : f4) * 16; }
+__host__ __device__ inline size_t team_tree_off(int tab_n, int n_sims, int kc) {
+    return (team_table_off(kc) + (size_t)tab_n * 8 + (size_t)(n_sims + 2) * 4 + 15) / 16 * 16;
 }
 
 // all of this workgroup's hand-off stores are on their way: drain, meet, one lane arrives
@@ -101,8 +102,11 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
 #define TADD(slot, a, b)
 #endif
 
-template <int ENV, int HP, bool GMM, int TLDS>
-__global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
+// KC: k-blocks per staged chunk of the tile routine; MINB: workgroups that have to fit a CU side by side (2: the default form,
+// 1024 trees at HP = 1024; 3 and 4 (shorter chunks: smaller stages, fewer registers): larger batches -- while one workgroup of a
+// CU waits at a hand-off or walks its trees, the others keep the matrix pipe busy).
+template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int NU = HP / 64, NCH = HP / 64;
     constexpr int TPW = 32 / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
                                         // trees), sqrt_tab [tab_n], pw_need [n_sims + 2], (LDS trees) the trees
     __shared__ float s_obs[32];         // [4 features][TPW] observations of this workgroup's new leaves, zero padded to a line
     __shared__ int s_ok;
-    double* s_sqrt = (double*)((char*)s_ab + team_table_off());
+    double* s_sqrt = (double*)((char*)s_ab + team_table_off(KC));
     int* s_pw = (int*)(s_sqrt + P.tab_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     // team and slice of this workgroup: the NU workgroups of a team have equal blockIdx % 8 (one XCD under round-robin placement)
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
     float* action = P.action + tb;
     TreeStore<TLDS> ts;
     if constexpr (TLDS != TS_GLOBAL) {
-        char* base = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims) + team_tree_bytes(P.R, CONT, TLDS) * (has_tree ? tj : 0);
+        char* base = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims, KC) + team_tree_bytes(P.R, CONT, TLDS) * (has_tree ? tj : 0);
         ts.hot = (Rec*)base;
         ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
         ts.prior = (float*)(base + (size_t)P.R * 16);
@@ -223,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void ls_team_kernel(KParams P, LockStep L, 
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
-            if (l == n_layers) ls_tile<HP, true, 2, 4, true>(P, L, l, in_buf, us, g0, s_ab, wt);
-            else ls_tile<HP, false, 2, 4, true>(P, L, l, in_buf, us, g0, s_ab, wt);
+            if (l == n_layers) ls_tile<HP, true, 2, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile<HP, false, 2, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
             if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;

@@ -7,15 +7,15 @@
 #include "team.cuh"
 
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
-template <int ENV, int HP, bool GMM, int TLDS>
-static hipError_t team_launch(azg_engine* e) {
+template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB>
+static hipError_t team_launch_form(azg_engine* e) {
     constexpr int NU = HP / 64, TPW = 32 / NU;
     constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
     const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
-    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
-    if (lds + 1024 > 160 * 1024) return hipErrorNotReady;
-    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS>;
+    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
+    if ((lds + 1024) * MINB > 160 * 1024) return hipErrorNotReady;
+    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB>;
     // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel)
     static std::atomic<int> per_cu_caches[AZG_MAX_DEVICES];
     static std::atomic<size_t> lds_caches[AZG_MAX_DEVICES];
@@ -33,7 +33,8 @@ static hipError_t team_launch(azg_engine* e) {
     // the occupancy query can answer one block per CU too many where the SGPR file is what limits residency; for 256-thread
     // blocks that limit is floor(800 / (ceil(sgpr / 16) * 16 + 16)) >= 6 whatever the kernel's sgpr count (<= 112): answers
     // up to 6 are safe to take as they are (and every wait in the kernel is bounded should this ever be wrong)
-    const int usable = per_cu < 6 ? per_cu : 6;
+    int usable = per_cu < 6 ? per_cu : 6;
+    if (usable > MINB) usable = MINB;   // (the form is built for MINB workgroups per CU; the next form takes larger batches)
     if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
     hipError_t rc = hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream);
     if (rc != hipSuccess) return rc;
@@ -46,7 +47,20 @@ static hipError_t team_launch(azg_engine* e) {
     e->kernel_form = 2;
     e->tree_lds = TLDS;
     e->dyn_lds = lds;
+    e->team_kc = KC; e->team_minb = MINB;
     return hipGetLastError();
+}
+
+// Two workgroups per CU with the long chunks while the batch fits that (1024 trees at HP = 1024: BASELINE config E per GPU); three,
+// then four per CU with short chunks for larger batches (HP = 1024, LDS trees: the shapes that were measured).
+template <int ENV, int HP, bool GMM, int TLDS>
+static hipError_t team_launch(azg_engine* e) {
+    hipError_t rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e);
+    if constexpr (HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV != AZG_ENV_CARTPOLE) {
+        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e);
+        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 4>(e);
+    }
+    return rc;
 }
 
 // trees in the workgroups' LDS when they fit (same rule as the persistent search kernel's), else in global memory

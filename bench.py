@@ -417,6 +417,10 @@ def main():
                              "ls_team_kernel<2, 1024, false, 1>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
                              "layer for the team's 32 trees each), hand-offs through global memory", dev),
+                extra_config("E's network at 2048 trees per GPU", PENDULUM, 2048, 200, 3, [1024] * 4, 2, "elu",
+                             "ls_team_kernel<2, 1024, false, 1, 2, 4>",
+                             mlp_flops(3, [1024] * 4, 3), "the team kernel's four-workgroups-per-CU form (short staging chunks): while one workgroup of a CU waits "
+                             "at a hand-off or walks its trees the other three keep the matrix pipe busy", dev),
             ]
         out = {
             "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",

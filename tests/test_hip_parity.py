@@ -622,3 +622,25 @@ def test_random_tie_break_is_the_same_on_the_device_and_the_oracle(native, kw):
     _assert_same(first, _tie_engine(O.OracleEngine, kw, "first"))
     if kw["mode"] == 0:
         assert not np.array_equal(a[0]["counts"], first[0]["counts"])   # (Pendulum's sampled actions make ties rare: no claim there)
+
+
+@pytest.mark.parametrize("B", [1536, 2048])
+def test_team_kernel_with_three_and_four_workgroups_per_cu(native, B, monkeypatch):
+    """Batches beyond two team workgroups per CU (config E's network with more than 1024 trees per GPU) run the team kernel's
+    short-chunk forms (three, then four workgroups per CU).  Same arithmetic as the per-layer launches: identical trees, record for
+    record (the launches are checked against the oracle at config E's size above); a ragged slice of the batch also against the oracle."""
+    NS = 24
+    kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+    desc = _capi.make_desc(3, [1024] * 4, 2, "elu")
+    blob = O.make_weights(34, 3, [1024] * 4, 2)
+    e = native.HipEngine(**kw)
+    roots = e.synthetic_roots()
+    e.close()
+    forms = []
+    a = _run(native.HipEngine, kw, desc, blob, roots, forms=forms)
+    monkeypatch.setenv("AZG_TEAM_WIDE", "0")
+    b = _run(native.HipEngine, kw, desc, blob, roots, forms=forms)
+    assert forms == [2, 1], forms                                  # team kernel, then the per-layer launches
+    _assert_same(a, b)
+    ro, do = _oracle_block(kw, desc, blob, roots, B - 40, B)
+    _assert_block_identical(a[0], a[1], ro, do, B - 40, B)
