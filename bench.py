@@ -227,7 +227,8 @@ def spawn(args):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--backend", args.backend]
+           "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--gather-every", str(args.gather_every),
+           "--backend", args.backend]
     for flag, on in (("--same-device", args.same_device), ("--config-d", args.config_d), ("--verify-gather", args.verify_gather)):
         if on:
             cmd.append(flag)
@@ -241,6 +242,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--trees", type=int, default=N_TREES, help="trees (games) per GPU")
     ap.add_argument("--bcast-every", type=int, default=10, help="N > 1: weight broadcast + engine re-sync every this many steps")
+    ap.add_argument("--gather-every", type=int, default=4, help="N > 1: replay rows are all-gathered in blocks of this many steps")
     ap.add_argument("--backend", default="nccl", help="N > 1: nccl (= RCCL) or gloo (functional test of the loop on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="N > 1: every rank on GPU 0 (functional test on a 1-GPU box, with gloo)")
     ap.add_argument("--config-d", action="store_true", help="run the N > 1 loop (self-play step + all-gather + weight broadcast) also with one rank: "
@@ -314,38 +316,35 @@ def main():
     else:
         # ---------------- config D: self-play steps + replay all-gather + weight broadcast
         from alphazero_gym_amd.agent.buffers import DeviceReplay
-        eng.selfplay_begin(200, capacity_steps=2, fifo=True)
-        ring = DeviceReplay(eng, batch_size=32).ring.reshape(2, B, -1)   # zero-copy torch view of the device ring
+        K = max(1, args.gather_every)
+        eng.selfplay_begin(200, capacity_steps=2 * K, fifo=True)
+        ring = DeviceReplay(eng, batch_size=32).ring.reshape(2, K * B, -1)   # zero-copy torch view of the device ring: two blocks of K steps
         RL = ring.shape[-1]
         on_host = args.backend != "nccl"
-        gathered = torch.empty((world * B, RL), dtype=torch.float32, device="cpu" if on_host else ring.device)
+        gathered = torch.empty((world * K * B, RL), dtype=torch.float32, device="cpu" if on_host else ring.device)
         flat = torch.from_numpy(blob.copy())
-
         d_flat = None if on_host else torch.from_numpy(blob.copy()).to(ring.device)
-        verify = {"checked": 0}
+        verify = {"checked": 0, "snap": None, "gathers": 0}
 
-        def gather(slot, expect=None):
-            rows = ring[slot]
+        def gather(block):
+            """all-gather one block of K finished steps (K * B rows per rank), HBM to HBM"""
+            rows = ring[block]
             dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
-            torch.cuda.current_stream().synchronize()         # the slot is free again before the step after next is launched
-            if expect is not None:
-                mine = gathered[rank * B:(rank + 1) * B]
-                assert torch.equal(mine.cpu(), expect), "the gathered block is not the block the previous step wrote"
+            torch.cuda.current_stream().synchronize()         # the block is free again before the steps that overwrite it are launched
+            verify["gathers"] += 1
+            if args.verify_gather:
+                mine = gathered[rank * K * B:(rank + 1) * K * B]
+                assert torch.equal(mine.cpu(), verify["snap"]), "the gathered block is not the block the last K steps wrote"
                 verify["checked"] += 1
 
         def run(steps, collectives):
-            """`steps` self-play steps; with collectives, the previous step's rows are all-gathered while this step searches.
-            The ring slot of a step comes from the engine's own account (azg_selfplay_ring: steps played since begin), not from
-            the loop index: the two-slot FIFO ring keeps turning across calls of this function."""
-            prev_slot, expect = None, None
+            """`steps` self-play steps; with collectives, every K steps the block of the K steps just finished is all-gathered
+            while the next step searches (fewer, larger collectives: K * B rows per rank and gather).  Which ring slots a step
+            writes comes from the engine's own account (azg_selfplay_ring: steps played since begin), not from the loop index:
+            the FIFO ring of 2 K steps keeps turning across calls of this function."""
             for s in range(steps):
                 eng.sync()                                        # the previous step finished (it ran while the host did the last gather)
-                if args.verify_gather and prev_slot is not None:
-                    # which slot did the previous step really write?  Compare the ring with its state before that step.
-                    now = ring.clone().cpu()
-                    changed = [i for i in range(2) if not torch.equal(now[i], verify["before"][i])]
-                    assert changed == [prev_slot], (changed, prev_slot)
-                    expect = now[prev_slot]
+                total = eng.selfplay_ring()[2]                    # steps played so far = index of the step about to be launched
                 if collectives and s > 0 and s % args.bcast_every == 0:
                     if on_host:                                   # functional run over gloo: staged through the host
                         dist.broadcast(flat, src=0)
@@ -354,16 +353,18 @@ def main():
                         dist.broadcast(d_flat, src=0)
                         torch.cuda.current_stream().synchronize()
                         eng.set_weights_device(desc, d_flat.data_ptr(), d_flat.numel())
-                if args.verify_gather:
-                    verify["before"] = ring.clone().cpu()
-                total = eng.selfplay_ring()[2]                    # steps played so far = the step about to be launched
+                full = collectives and total > 0 and total % K == 0   # steps total - K .. total - 1 fill one block, all finished
+                if full and args.verify_gather:
+                    # the rows those K steps wrote, found without the slot formula: the block that differs from the snapshot taken
+                    # K steps ago; it must be the one that is about to be gathered
+                    now = ring.clone().cpu()
+                    if verify.get("before") is not None:
+                        changed = [i for i in range(2) if not torch.equal(now[i], verify["before"][i])]
+                        assert changed == [(total // K - 1) % 2], (changed, total, K)
+                    verify["snap"], verify["before"] = now[(total // K - 1) % 2], now
                 eng.selfplay_step()                               # launches only: this step now runs on the engine's stream
-                if collectives and prev_slot is not None:
-                    gather(prev_slot, expect)
-                prev_slot = total % 2                             # capacity 2, FIFO: step k lives in slot k % 2
-            eng.sync()
-            if collectives and prev_slot is not None:
-                gather(prev_slot, ring[prev_slot].clone().cpu() if args.verify_gather else None)
+                if full:
+                    gather((total // K - 1) % 2)                  # FIFO, capacity 2 K: step k lives in slot k % 2K, block (k / K) % 2
 
         run(args.warmup, True)
         barrier()
@@ -376,12 +377,14 @@ def main():
         run(args.steps, False)
         barrier()
         plain = time.perf_counter() - t1
-        counts = gathered[:, 3 + eng.kmax:3 + 2 * eng.kmax].sum(1)
-        assert bool((counts == N_SIMS).all()), "a gathered replay row does not hold n_sims visits"
+        if verify["gathers"]:
+            counts = gathered[:, 3 + eng.kmax:3 + 2 * eng.kmax].sum(1)
+            assert bool((counts == N_SIMS).all()), "a gathered replay row does not hold n_sims visits"
         kmed, kmean = time_search(eng, 5, 0)
         workload = (f"config D: Pendulum-v1 A0C self-play, {world * B} games = {B} per GPU x {N_SIMS} sims per move, 2x256 ELU MLP; per step: "
-                    f"search + final action + env step + replay row on the device, all-gather of the step's {world * B} replay rows "
-                    f"({world * B * RL * 4 / 1e6:.1f} MB) and a weight broadcast + engine re-sync every {args.bcast_every} steps")
+                    f"search + final action + env step + replay row on the device; every {K} steps an all-gather of those steps' "
+                    f"{world * K * B} replay rows ({world * K * B * RL * 4 / 1e6:.1f} MB, HBM to HBM, beside the next step's search); a weight "
+                    f"broadcast + engine re-sync (device to device) every {args.bcast_every} steps")
         parallelism = f"{world} ranks x {B} games (games sharded by global id; RCCL all-gather + broadcast outside the search)"
         if args.backend != "nccl":
             parallelism += f" [functional run: backend {args.backend}, rows staged through the host]"
@@ -401,7 +404,8 @@ def main():
         if config_d:
             extra["search_only"] = {"sims_per_s": sims / plain, "ms_per_step": plain / args.steps * 1e3,
                                     "note": "the same self-play loop without the all-gather and the weight broadcast"}
-            extra["collectives"] = {"backend": args.backend, "world_size": world, "gathers_verified": verify["checked"],
+            extra["collectives"] = {"backend": args.backend, "world_size": world, "gather_every": K, "gathers": verify["gathers"],
+                                    "gathers_verified": verify["checked"],
                                     "weight_sync": "host (gloo functional run)" if on_host else "device to device: RCCL broadcast into HBM + azg_set_weights_device"}
         elif not args.no_extra:
             extra["configs"] = [

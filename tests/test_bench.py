@@ -52,10 +52,12 @@ def test_gathered_rows_are_the_previous_steps_rows(warmup):
     """The two-slot replay ring keeps turning across the warm-up, the timed loop and the collective-free loop; the slot that is
     all-gathered while step s searches must be the one step s - 1 wrote, whatever the parity of the warm-up (with an
     odd warm-up the loop used to gather the slot being overwritten).  --verify-gather finds the slot a step wrote by comparing
-    the ring before and after it and checks every gathered block against it."""
-    out = _bench_json(["--gpus", "2", "--steps", "5", "--warmup", str(warmup), "--trees", "256", "--bcast-every", "2", "--backend", "gloo",
-                       "--same-device", "--verify-gather"])
-    assert out["extra"]["collectives"]["gathers_verified"] >= warmup + 5 - 2   # (a run of k steps gathers k blocks)
+    the ring before and after it and checks every gathered block against it.  (Rows are gathered in blocks of --gather-every
+    steps; the ring holds two blocks.)"""
+    out = _bench_json(["--gpus", "2", "--steps", "5", "--warmup", str(warmup), "--trees", "256", "--bcast-every", "2", "--gather-every", "2",
+                       "--backend", "gloo", "--same-device", "--verify-gather"])
+    c = out["extra"]["collectives"]
+    assert c["gathers_verified"] == c["gathers"] >= (warmup + 5 - 1) // 2   # a block of two finished steps per gather, across both runs
 
 
 @pytest.mark.gpu
@@ -64,10 +66,10 @@ def test_config_d_loop_over_rccl_with_one_rank():
     engine-owned ring (the zero-copy view azg_selfplay_rows_device exports) and the weight broadcast into HBM followed by
     azg_set_weights_device go through RCCL with world size 1.  Proves RCCL accepts engine-owned memory and that the stream
     ordering between the engine's stream and RCCL's holds (every gathered block verified), before a multi-GPU node sees it."""
-    out = _bench_json(["--gpus", "1", "--config-d", "--steps", "6", "--warmup", "3", "--trees", "1024", "--bcast-every", "2", "--backend", "nccl",
-                       "--verify-gather"])
+    out = _bench_json(["--gpus", "1", "--config-d", "--steps", "6", "--warmup", "3", "--trees", "1024", "--bcast-every", "2", "--gather-every", "2",
+                       "--backend", "nccl", "--verify-gather"])
     assert out["n_gpus"] == 1 and "config D" in out["config"]["workload"]
     c = out["extra"]["collectives"]
-    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["gathers_verified"] >= 6 + 3 - 2
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["gathers_verified"] == c["gathers"] >= 4
     assert c["weight_sync"].startswith("device to device")
     assert out["value"] > 0
