@@ -1,4 +1,6 @@
 """GPU (-m gpu): the HIP engine against the CPU oracle and the reference's golden vectors, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -461,9 +463,14 @@ def _random_case(rng):
             ncomp = int(rng.integers(2, 6))
         in_dim, n_dist = 3, (3 * ncomp if ncomp else 2)
         mode = 1
-    else:
+    elif rng.random() < 0.65:
         env, mode, in_dim, n_dist = 0, 0, 4, 2
         extra.update(c_uct=float(rng.choice([1.5, 5.0, 30.0])), num_actions=2)
+    else:   # three actions (gym MountainCar-v0)
+        env, mode, in_dim, n_dist = 3, 0, 2, 3
+        extra.update(c_uct=float(rng.choice([0.8, 2.0, 6.0])), num_actions=3)
+    if mode == 0 and rng.random() < 0.2:
+        extra["tie_break"] = "random"
     return env, mode, hidden, act, ln, n_sims, extra, ncomp, in_dim, n_dist
 
 
@@ -475,6 +482,13 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     env, mode, hidden, act, ln, n_sims, extra, ncomp, in_dim, n_dist = _random_case(rng)
     B = int(rng.choice([1, 5, 16, 19, 33]))
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=int(rng.integers(1, 1 << 30)), tree_id_base=int(rng.integers(0, 1000)), **extra)
+    if os.environ.get("AZG_FUZZ_SHAPES"):   # tools/fuzz_parity.py: also the 8-wave workgroup shapes, global trees, weights from L2
+        os.environ.pop("AZG_WAVES", None); os.environ.pop("AZG_GROUPS", None); os.environ.pop("AZG_FORCE_GLOBAL_TREE", None); os.environ.pop("AZG_FORCE_STREAM_WEIGHTS", None)
+        pick = int(rng.integers(0, 6))
+        if pick == 1: os.environ["AZG_WAVES"] = "8"
+        if pick == 2: os.environ["AZG_GROUPS"] = "2"
+        if pick == 3: os.environ["AZG_FORCE_GLOBAL_TREE"] = "1"
+        if pick == 4: os.environ["AZG_FORCE_STREAM_WEIGHTS"] = "1"
     desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
     blob = O.make_weights(int(rng.integers(1, 1000)), in_dim, hidden, n_dist, scale=float(rng.choice([1.0, 2.0, 3.0])))
     if ln:
