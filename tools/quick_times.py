@@ -23,6 +23,8 @@ SHAPES = {
 
 def main():
     for name in (sys.argv[1:] or ["C", "C8192", "B"]):
+        if name.startswith("X"):   # X<trees>: config E's network at that many trees
+            SHAPES[name] = (PEND, int(name[1:]), 200, 3, [1024] * 4, "elu")
         kw, B, ns, ind, hidden, act = SHAPES[name]
         e = _native.HipEngine(n_trees=B, n_sims=ns, **kw)
         e.set_weights(_capi.make_desc(ind, hidden, 2, act), make_weights(34, ind, hidden, 2))

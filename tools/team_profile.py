@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 from alphazero_gym_amd import _capi, _native  # noqa: E402
 from alphazero_gym_amd.synthetic import make_weights  # noqa: E402
 
-B, NS = 1024, 200
+B, NS = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 200
 e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
 e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), make_weights(34, 3, [1024] * 4, 2))
 e.upload_roots(e.synthetic_roots())
@@ -29,12 +29,12 @@ assert lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), row
 w = buf.reshape(-1, 8).astype(np.float64) / (NS + 1)     # [workgroup = team * 16 + slice][slot], cycles per step
 names = ["wait for observations", "tile layer 1 (+ layer 0)", "tile layer 2", "tile layer 3", "arrive + wait between layers",
          "wait for the last layer", "tree phases", "whole loop"]
-tree = np.zeros(len(w), bool)
-tree[0::16] = True
-tree[1::16] = True
-for kind, m in (("tree workgroups", tree), ("other workgroups", ~tree)):
-    print(kind)
-    for i, nm in enumerate(names):
-        v = w[m, i]
-        print(f"  {nm:30s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles/step")
+n_wg = (B + 31) // 32 * 16                                  # teams of 32 trees x 16 workgroups (HP = 1024)
+w = w[:n_wg]
+name = C.create_string_buffer(256)
+lib.azg_debug_kernel_name(C.c_void_p(e._h.value), name, C.c_size_t(256))
+print("kernel", name.value.decode(), "workgroups", n_wg)
+for i, nm in enumerate(names):
+    v = w[:, i]
+    print(f"  {nm:30s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles/step")
 print("per step at 2.4 GHz:", w[:, 7].mean() / 2400, "us")
