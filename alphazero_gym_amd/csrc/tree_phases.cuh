@@ -453,6 +453,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
         }
         // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
+        STAMP(tw1);
+        STAMP_ADD(14, tb1, tw1);   // widening (noise, policy parameters, tanh, edge record, child list)
         st.path_D += 1;
         double ns[S], r, sn;
         int done;
@@ -472,6 +474,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         }
         float obs[4];
         env_obs<ENV>(ns, obs, &sn);
+        STAMP(tw2);
+        STAMP_ADD(15, tw1, tw2);   // env step + observation
         if (sub == 0) {
             Cold c;
 #pragma unroll

@@ -57,6 +57,8 @@ def main():
     lv = max(b[:, 12].sum(), 1)
     print(f"  B: whole descent           mean {b[:, 13].mean() / (n_sims + 1):9.0f} cycles/step, {b[:, 12].mean() / (n_sims + 1):.2f} completed levels per step "
           f"(wave-level: max over the wave's trees)")
+    for i, nm in ((14, "widening (noise, tanh, edge, child list)"), (15, "env step + observation")):
+        print(f"  B: after the descent: {nm:42s} mean {b[:, i].mean() / (n_sims + 1):9.0f} cycles/step")
     for i, nm in ((11, "full level"), (7, "child records + division + U"), (8, "scores + arg-max"), (9, "chosen record"), (10, "path slot + cold prefetch")):
         print(f"  B: per level: {nm:30s} {b[:, i].sum() / lv:8.0f} cycles")
 
