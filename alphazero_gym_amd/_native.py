@@ -1,9 +1,7 @@
 """Loads the HIP engine (csrc/libazgym_hip.so).  There is NO CPU fallback: if the library is missing or a GPU
 is not present, constructing an engine raises."""
 import ctypes as C
-import importlib.util
 import os
-import sys
 
 from . import _capi
 
@@ -19,25 +17,6 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
-def _preload_torch_hip_runtime():
-    """Load the HIP / HSA runtime copies that an installed torch package bundles (torch/lib), globally, so that this engine and a
-    torch imported afterwards share one runtime.  Nothing happens when torch is not installed or bundles no runtime."""
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
-    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return   # (torch's own import will sort its libraries out; the engine then uses the system runtime)
-
-
 def lib():
     global _lib, _fns
     if _lib is None:
@@ -48,10 +27,13 @@ def lib():
             )
         # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's), and the
         # dynamic linker gives every later library whichever copy was loaded first.  If this engine came first and pulled in the
-        # system runtime, a later torch.cuda initialisation would fail ("No HIP GPUs are available").  So when a torch package is
-        # installed, ITS runtime is loaded first -- by path, without importing torch (an application may import it later, or never).
-        if "torch" not in sys.modules:
-            _preload_torch_hip_runtime()
+        # system runtime, a later torch.cuda initialisation fails ("No HIP GPUs are available"); so torch, when present, goes first.
+        # (Round 3 tried loading torch's runtime copy by path instead of importing torch: engine-first then worked in one GPU run
+        # and hung in torch's CUDA initialisation in the next -- reverted.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _fns = _capi.bind(_lib, "azg_")
         ver = _fns["abi_version"]()

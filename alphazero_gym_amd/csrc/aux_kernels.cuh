@@ -2,6 +2,8 @@
 #pragma once
 #include "records.h"
 #include "env.cuh"
+#include "tree.cuh"
+#include "results.cuh"
 
 // ------------------------------------------------------------------------------------------------ result gathering
 
@@ -40,71 +42,19 @@ struct RootView {
     __device__ __forceinline__ float act(int a) const { if (staged) return k->act[a]; int i = id(a); return cont ? P.action[tb + (i >= 0 ? i : 0)] : (float)a; }
 };
 
-// MCTS.return_results (mcts.py:269-307) from the published (global) trees: 16 lanes per tree, lane a = root child a (a + 16, ... for
-// roots with more children), 16 trees per workgroup.  Everything that is written per child is independent across lanes; the
-// root's totals are row reductions that do not depend on the order (integer sum, maximum); the on-policy value target, whose
-// float64 sum is order-sensitive, is added up by the tree's first lane in the reference's order.
+// The same for all trees from their published (global) form: 16 trees per workgroup.
 #define RS_TREES 16
-__global__ __launch_bounds__(16 * RS_TREES) void results_kernel(KParams P, int Kmax, int v_target, float* actions, int* counts, double* Q, double* vt,
-                                                                int* nch, int* child_n, double* child_state, float* root_V, float* root_dist) {
+__global__ __launch_bounds__(16 * RS_TREES) void results_kernel(KParams P) {
     const int sub = threadIdx.x & 15;
     const int tree = blockIdx.x * RS_TREES + (threadIdx.x >> 4);
     if (tree >= P.B) return;
     const size_t tb = (size_t)tree * P.R;
-    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
-    const RecL* hot = P.hot + tb;
-    const RecL root = hot[0];
-    const int nc = root.n_child;
-    int tot_l = 0;
-    double qmax_l = -__builtin_huge_val();
-    for (int a = sub; a < Kmax; a += 16) {
-        const int k = a < nc ? (cont ? (int)P.child[tb * P.Kp + a] : (int)root.first + a) : -1;
-        const RecL h = hot[k >= 0 ? k : 0];
-        const size_t o = (size_t)tree * Kmax + a;
-        actions[o] = k >= 0 ? (cont ? P.action[tb + k] : (float)a) : 0.0f;
-        counts[o] = k >= 0 ? h.edge_n : 0;
-        Q[o] = k >= 0 ? h.Q : 0.0;
-        const bool ex = k >= 0 && (h.flags & FLAG_EXPANDED);
-        child_n[o] = ex ? h.node_n : -1;
-        for (int s2 = 0; s2 < P.S; ++s2) child_state[o * P.S + s2] = ex ? P.cold[tb + k].s[s2] : 0.0;
-        if (k >= 0) { tot_l += h.edge_n; qmax_l = h.Q > qmax_l ? h.Q : qmax_l; }
-    }
-    // row totals (order-independent)
-    for (int m = 1; m < 16; m <<= 1) {
-        tot_l += __shfl_xor(tot_l, m, 16);
-        const double o = __shfl_xor(qmax_l, m, 16);
-        qmax_l = o > qmax_l ? o : qmax_l;
-    }
-    if (sub == 0) {
-        const double qmax = nc > 0 ? qmax_l : 0.0;
-        double onp = 0.0;
-        if (v_target == AZG_VT_ON_POLICY) {
-            auto kid = [&](int a) { return hot[cont ? (int)P.child[tb * P.Kp + a] : (int)root.first + a]; };
-            const long tot = tot_l;
-            if (!cont) {
-                for (int a = 0; a < nc; ++a) { const RecL h = kid(a); onp += ((double)h.edge_n / (double)tot) * h.Q; }
-            } else {
-                // reference quirk (mcts.py:111 with Q of shape (K,1)): the K x K outer product is summed
-                for (int a = 0; a < nc; ++a) {
-                    const double qa = kid(a).Q;
-                    for (int b2 = 0; b2 < nc; ++b2) onp += ((double)kid(b2).edge_n / (double)tot) * qa;
-                }
-            }
-        }
-        vt[tree] = v_target == AZG_VT_ON_POLICY ? onp : qmax;
-        nch[tree] = nc;
-        root_V[tree] = P.cold[tb].V;
-    }
-    if (cont && P.ncomp >= 2) {
-        for (int i = sub; i < 3 * P.ncomp; i += 16) {
-            const int part = i / P.ncomp, c = i % P.ncomp;
-            root_dist[(size_t)tree * 3 * P.ncomp + i] = P.gmm[tb * 3 * GMM_MAXC + part * GMM_MAXC + c];
-        }
-    } else if (cont) {
-        if (sub == 0) { root_dist[(size_t)tree * 2] = P.cold[tb].mu; root_dist[(size_t)tree * 2 + 1] = P.cold[tb].sg; }
-    } else {
-        for (int d = sub; d < P.nd; d += 16) root_dist[(size_t)tree * P.nd + d] = P.prior[tb + root.first + d];
-    }
+    TreeStore<TS_GLOBAL> ts;
+    ts.hot = P.hot + tb;
+    ts.child = P.child + tb * P.Kp;
+    ts.prior = P.prior + tb;
+    if (P.mode == AZG_MODE_CONTINUOUS) results_for_tree<true, TS_GLOBAL>(P, ts, P.cold + tb, P.action + tb, tb, tree, sub);
+    else results_for_tree<false, TS_GLOBAL>(P, ts, P.cold + tb, P.action + tb, tb, tree, sub);
 }
 
 // One self-play step after a search, one thread per game: replay row, the agent's final action rule, the real env step,

@@ -278,6 +278,9 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     P.roots = e->d_roots; P.carry = e->d_carry;
     P.hot = hot; P.cold = cold; P.edge_W = edge_W; P.action = action; P.prior = prior; P.child = child;
     P.n_rec = n_rec; P.pw_need = d_pw; P.sqrt_tab = d_sq;
+    P.res_actions = e->d_actions; P.res_counts = e->d_counts; P.res_Q = e->d_Q; P.res_vt = e->d_vt; P.res_nch = e->d_nch;
+    P.res_child_n = e->d_child_n; P.res_child_state = e->d_child_state; P.res_root_V = e->d_rootV; P.res_root_dist = e->d_rootdist;
+    P.res_Kmax = e->Kmax; P.res_v_target = cfg->v_target;
     *out = e;
     return AZG_OK;
 #undef CK
@@ -500,7 +503,7 @@ static int set_weights_impl(azg_engine* e, const azg_mlp_desc* d, const float* b
         if (ncomp) { if (dalloc(e, &g, (size_t)e->cfg.n_trees * e->R * 3 * GMM_MAXC, e->dist_allocs)) return AZG_E_DEVICE; }
         float* rd = nullptr;
         if (dalloc(e, &rd, (size_t)e->cfg.n_trees * d->n_dist, e->dist_allocs)) return AZG_E_DEVICE;
-        e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
+        e->P.gmm = g; e->P.ncomp = ncomp; e->d_rootdist = rd; e->P.res_root_dist = rd; e->nd = d->n_dist; e->P.nd = d->n_dist;
         e->dist_nd = d->n_dist; e->dist_ncomp = ncomp;
     }
     const int n_out = 1 + d->n_dist;
@@ -581,7 +584,7 @@ int azg_search_resident(azg_engine* e) {
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;
     e->searched = 1;
-    e->results_valid = 0;
+    e->results_valid = e->kernel_form == 0 ? 1 : 0;   // the one-launch search kernel writes return_results in its epilogue
     return AZG_OK;
 }
 
@@ -623,8 +626,7 @@ static int launch_results(azg_engine* e) {
         if (trc) return trc;
     }
     int B = e->cfg.n_trees;
-    hipLaunchKernelGGL(results_kernel, dim3((B + RS_TREES - 1) / RS_TREES), dim3(16 * RS_TREES), 0, e->stream, e->P, e->Kmax, e->cfg.v_target, e->d_actions,
-                       e->d_counts, e->d_Q, e->d_vt, e->d_nch, e->d_child_n, e->d_child_state, e->d_rootV, e->d_rootdist);
+    hipLaunchKernelGGL(results_kernel, dim3((B + RS_TREES - 1) / RS_TREES), dim3(16 * RS_TREES), 0, e->stream, e->P);
     HIPCHK(e, hipGetLastError());
     e->results_valid = 1;   // (in stream order: whatever reads the buffers is ordered after this launch)
     return AZG_OK;

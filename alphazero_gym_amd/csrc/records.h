@@ -105,6 +105,10 @@ struct KParams {
     int Htrue[MAX_STREAM_LAYERS];          // true (unpadded) width of trunk layer l
     const f32x4* lng[MAX_STREAM_LAYERS];   // LayerNorm weight of trunk layer l, [HP/16][64] (D-register layout, zero padded)
     const f32x4* lnb[MAX_STREAM_LAYERS];   // LayerNorm bias
+    // MCTS.return_results of every tree (aux_kernels.cuh: results_for_tree), written by the search kernel's epilogue or results_kernel
+    float* res_actions; int* res_counts; double* res_Q; double* res_vt; int* res_nch; int* res_child_n; double* res_child_state;
+    float* res_root_V; float* res_root_dist;
+    int res_Kmax, res_v_target;
     int tie_random;             // AZG_TIE_RANDOM: exactly equal selection scores are broken by a Philox draw instead of by lowest index
     int env_id;                 // AZG_ENV_* (the discrete family's kernels serve CartPole and MountainCar: env step chosen at run time)
     int lds_state;              // discrete LDS trees: the env states of expanded nodes live in LDS too (set by the launch planning)

@@ -10,6 +10,7 @@
 #include "mlp.cuh"
 #include "tree.cuh"
 #include "tree_phases.cuh"
+#include "results.cuh"
 
 // Dynamic LDS layout of a workgroup, shared by the kernel and the host's launch planning
 struct LdsLayout {
@@ -191,6 +192,8 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
 #ifdef AZG_STAMPS
     if (lane == 0) for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * NW + wave) * 16 + i] = st_acc[i];
 #endif
+    // MCTS.return_results (mcts.py:269-307) straight from the trees as they stand (LDS or global): no second launch
+    if (live) results_for_tree<CONT, TLDS>(P, ts, cx.cold, cx.action, tb, tree, sub);
     if (live) {
         if (sub == 0) P.n_rec[tree] = nrec;
         if constexpr (TLDS != TS_GLOBAL) {
