@@ -6,8 +6,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N = 1  (config C): a "step" is one whole search (4096 trees x 200 simulations = ONE launch of the fused search kernel) over
-       synthetic fixed-seed root states already resident in HBM, plus return_results for every tree into device buffers
-       (azg_results_resident: one small launch, no copy).  The JSON line also carries `extra`: configs B and E timed
+       synthetic fixed-seed root states already resident in HBM, return_results of every tree included (written into device
+       buffers by the search kernel's epilogue; azg_results_resident hands them out, no copy).  The JSON line also carries `extra`: configs B and E timed
        the same way, the PCIe-inclusive rate of config C, and the CPU baselines.
        `--config-d` runs the N > 1 loop (below) with one rank: the collectives then go through RCCL with world size 1.
 N > 1  (config D): one process per GPU (spawned here when the script was not started by torch.distributed.run), 4096 self-play
@@ -297,7 +297,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.search_resident()      # the whole search: one launch
-            eng.results_resident()     # return_results of every tree into device buffers: one small launch, no copy
+            eng.results_resident()     # return_results of every tree: device buffers written by the search kernel's epilogue, no copy
         eng.sync()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -440,7 +440,7 @@ def main():
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (" + str(profiled_traffic()[1]) + "), not measured in this run; `value` is wall "
-                                 "time over K steps of search + return_results (results_kernel) with everything resident in HBM, the PCIe-inclusive "
+                                 "time over K steps of search + return_results (written by the same launch's epilogue) with everything resident in HBM, the PCIe-inclusive "
                                  "rate is extra.pcie_inclusive"},
             "extra": extra,
         }
