@@ -801,6 +801,10 @@ T7_CASES = {
     "cartpole_maxvalue": dict(env_id=0, mode=0, num_actions=2, n_sims=16, c_uct=5.0, gamma=0.97, epsilon=0.0, v_target="off_policy",
                               hidden=[64], act="relu", wseed=8, wscale=2.0, seed=16, tree_id_base=0, n_games=3, n_steps=10, max_len=7,
                               det=False, final_selection="max_value"),
+    # three actions (gym MountainCar-v0): sampled final action, tree reuse through mcts_forward, episodes cut by length
+    "mountaincar_sampled": dict(env_id=3, mode=0, num_actions=3, n_sims=18, c_uct=2.0, gamma=0.98, epsilon=0.0, v_target="off_policy",
+                                hidden=[64, 64], act="relu", wseed=9, wscale=3.0, seed=17, tree_id_base=3, n_games=3, n_steps=16, max_len=7,
+                                det=False),
 }
 
 
@@ -812,7 +816,7 @@ def run_t7(case):
     import alphazero.agent.agents as RA
     from alphazero.agent.buffers import ReplayBuffer
     cont = case["mode"] == 1
-    in_dim = 3 if cont else 4
+    in_dim = 3 if cont else (2 if case["env_id"] == 3 else 4)
     n_dist = 2 if cont else case["num_actions"]
     seed = case["seed"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
@@ -862,7 +866,7 @@ def run_t7(case):
                                             kappa=case["kappa"], gamma=case["gamma"], epsilon=case["epsilon"],
                                             V_target_policy=case["v_target"], device="cpu", root_state=None)
             else:
-                env = CartPoleEnv()
+                env = MountainCarEnv() if case["env_id"] == 3 else CartPoleEnv()
                 ag = object.__new__(RA.DiscreteAgent)
                 ag.final_selection = fs; ag.temperature = case.get("temperature", 1.0)
                 ag.mcts = RM.MCTSDiscrete(model=None, num_actions=case["num_actions"], n_rollouts=case["n_sims"], c_uct=case["c_uct"],
@@ -872,7 +876,7 @@ def run_t7(case):
             step, episode = 0, 0
             while step < n_steps:
                 # Env.reset() (run_*.py: `state = Env.reset()`), with the engine's reset state of (game, episode)
-                rs = O.reset_state(seed, gt, episode, not cont)
+                rs = O.reset_state(seed, gt, episode, not cont, env_id=case["env_id"])
                 env.state = np.asarray(rs, np.float64) if cont else tuple(float(v) for v in rs)
                 state = env._get_obs() if cont else np.array(env.state, dtype=np.float32)
                 R = 0.0
@@ -923,7 +927,7 @@ def run_t7(case):
                 episode += 1
                 if step >= n_steps:
                     # the device resets the game in the same step that ends the episode
-                    final_state[g] = O.reset_state(seed, gt, episode, not cont)
+                    final_state[g] = O.reset_state(seed, gt, episode, not cont, env_id=case["env_id"])
             assert len(buffer) == n_steps
             # the buffer holds what the rows hold (buffer.store is the reference's own)
             for i, exp in enumerate(buffer.experience):
@@ -936,8 +940,10 @@ def run_t7(case):
                 final_state=final_state, case=np.array(repr(case)))
 
 
-def main_t7():
+def main_t7(only=None):
     for name, case in T7_CASES.items():
+        if only and name not in only:
+            continue
         TIES["n"] = 0
         t7 = run_t7(case)
         assert TIES["n"] == 0, f"t7 {name}: argmax tie occurred in the reference run; pick other inputs"
@@ -946,8 +952,8 @@ def main_t7():
 
 
 def main():
-    if sys.argv[1:] == ["t7"]:   # only the self-play tier (the other fixtures are left untouched)
-        return main_t7()
+    if sys.argv[1:2] == ["t7"]:   # only the self-play tier, or only its named cases (the other fixtures are left untouched)
+        return main_t7(sys.argv[2:])
     if sys.argv[1:2] == ["t1"]:   # only the named T1 cases: python gen_golden.py t1 t1_mountaincar_default ...
         for name in sys.argv[2:]:
             TIES["n"] = 0

@@ -81,7 +81,7 @@ def _engine_cls(which):
 
 def _t7_engine(cls, case, **over):
     cont = case["mode"] == 1
-    in_dim, n_dist = (3, 2) if cont else (4, case["num_actions"])
+    in_dim, n_dist = (3, 2) if cont else (2 if case["env_id"] == 3 else 4, case["num_actions"])
     e = cls(env_id=case["env_id"], mode=case["mode"], n_trees=case["n_games"], n_sims=case["n_sims"], c_uct=case["c_uct"],
             gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0), c_pw=case.get("c_pw", 1.0),
             kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=case["seed"], tree_id_base=case["tree_id_base"])
