@@ -71,6 +71,142 @@ struct SelfPlay {
     double* roots; int* carry;
 };
 
+// The common case (at most 16 root children: every LDS-tree configuration): 16 lanes per game, lane a = root child a.  The replay
+// row is written by the lanes side by side; totals are row reductions that do not depend on the order (integer sum, maximum,
+// first index of the largest count); everything whose float64 order matters (on-policy target, normaliser sums, the inverse-CDF
+// walk of numpy's random.choice) is added up by the game's first lane in the reference's order, reading the lanes' values by
+// shuffles; that lane also steps the env and keeps the episode's books.  Same arithmetic as selfplay_kernel below (roots with
+// more children) and as the oracle.
+#define SP_TREES 16
+__global__ __launch_bounds__(16 * SP_TREES) void selfplay_kernel16(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
+    const int sub = threadIdx.x & 15;
+    const int tree = blockIdx.x * SP_TREES + (threadIdx.x >> 4);
+    if (tree >= P.B) return;
+    const size_t tb = (size_t)tree * P.R;
+    const RecL* hot = P.hot + tb;
+    const bool cont = P.mode == AZG_MODE_CONTINUOUS;
+    const unsigned gtree = (unsigned)(P.tree_base + tree);
+    const int S = P.S, K = Kmax, RL = S_obs + 3 * Kmax + 1;
+    float* row = sp.rows + (size_t)tree * RL;
+    const RecL r0 = hot[0];
+    const int nc = r0.n_child;
+    // lane a: root child a
+    const bool has = sub < nc;
+    const int kid = has ? (cont ? (int)P.child[tb * P.Kp + sub] : (int)r0.first + sub) : 0;
+    const RecL h = hot[kid];
+    const float act = has ? (cont ? P.action[tb + kid] : (float)sub) : 0.0f;
+    if (sub < K) {
+        row[S_obs + sub] = act;
+        row[S_obs + K + sub] = has ? (float)h.edge_n : 0.0f;
+        row[S_obs + 2 * K + sub] = has ? (float)h.Q : 0.0f;
+    }
+    int tot = has ? h.edge_n : 0;
+    double qmax = has ? h.Q : -__builtin_huge_val();
+    int ckey = has ? ((h.edge_n << 4) | (15 - sub)) : -1;          // largest count, lowest index on ties (counts < 2^27)
+    for (int m = 1; m < 16; m <<= 1) {
+        tot += __shfl_xor(tot, m, 16);
+        const double o = __shfl_xor(qmax, m, 16);
+        qmax = o > qmax ? o : qmax;
+        const int ok = __shfl_xor(ckey, m, 16);
+        ckey = ok > ckey ? ok : ckey;
+    }
+    if (nc == 0) qmax = 0.0;
+    const int cmax = ckey >> 4, amax = 15 - (ckey & 15);
+    // discrete: the lane's unnormalised pi entry (stable_normalizer's x / max(x), to the temperature)
+    double x = 0.0;
+    if (!cont && has) {
+        if (sp.final_selection == AZG_FS_MAX_VALUE) x = h.Q / qmax;
+        else x = sp.ctab ? sp.ctab[(size_t)cmax * (cmax + 1) / 2 + h.edge_n] : (double)h.edge_n / (double)cmax;
+    }
+    // ---- the game's first lane: order-sensitive sums, the final action, the env step, the books (the shuffles are executed by
+    // the whole row: loop bounds are row-uniform)
+    double onp = 0.0;
+    if (v_target == AZG_VT_ON_POLICY) {
+        if (!cont) {
+            for (int a = 0; a < nc; ++a) onp += ((double)__shfl(h.edge_n, a, 16) / (double)tot) * __shfl(h.Q, a, 16);
+        } else {
+            for (int a = 0; a < nc; ++a) {
+                const double qa = __shfl(h.Q, a, 16);
+                for (int b2 = 0; b2 < nc; ++b2) onp += ((double)__shfl(h.edge_n, b2, 16) / (double)tot) * qa;
+            }
+        }
+    }
+    int pick = 0;
+    if (cont) {
+        // ContinuousAgent.act (agents.py:524-535): actions[Qs.argmax()] / actions[counts.argmax()], first index on ties
+        pick = amax;
+        if (sp.final_selection == AZG_FS_MAX_VALUE) {
+            double qb = 0.0;
+            for (int a = 0; a < nc; ++a) { const double q = __shfl(h.Q, a, 16); if (a == 0 || q > qb) { qb = q; pick = a; } }
+        }
+        if (sp.agent_eps != 0.0) {
+            // epsilon_greedy (agents.py:471-490): random.random() < epsilon -> np.random.choice(actions)
+            azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+            if ((double)azg_u01(b.v[0]) < sp.agent_eps) pick = (int)(b.v[1] % (unsigned)nc);
+        }
+    } else {
+        // DiscreteAgent.act (agents.py:294-301): pi = stable_normalizer(Qs | counts, temperature) (helpers.py:26-27), then
+        // pi.argmax() or np.random.choice(len(pi), p=pi) (cdf = cumsum(pi); cdf /= cdf[-1]; first index with u < cdf)
+        double sum = 0.0;
+        for (int a = 0; a < nc; ++a) sum = sum + __shfl(x, a, 16);
+        const double pi = has ? __builtin_fabs(x / sum) : 0.0;
+        double best = 0.0, cum = 0.0;
+        for (int a = 0; a < nc; ++a) {
+            const double pa = __shfl(pi, a, 16);
+            if (a == 0 || pa > best) { best = pa; pick = a; }
+            cum = cum + pa;
+        }
+        if (!sp.deterministic) {
+            azg_u32x4 b = azg_draw(P.seed, gtree, sp.step_idx, 0u, AZG_STREAM_ACT);
+            const double u = ((double)b.v[0] + 0.5) * (1.0 / 4294967296.0);
+            const double last = cum;
+            double c = 0.0;
+            pick = nc - 1;
+            bool found = false;
+            for (int a = 0; a < nc; ++a) {
+                const double pa = __shfl(pi, a, 16);
+                if (!found) {
+                    c = c + pa;
+                    if (u < c / last) { pick = a; found = true; }
+                }
+            }
+        }
+    }
+    const float pact = __shfl(act, pick, 16);
+    const int pnode_n = __shfl(h.node_n, pick, 16), pflags = __shfl((int)h.flags, pick, 16);
+    if (sub != 0) return;
+    double root[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < S; ++k) root[k] = sp.roots[(size_t)tree * S + k];
+    float obs[4];
+    double sn;
+    // (the discrete family's observation is its state as float32: MountainCar's unused slots 2..3 are zero)
+    if (!cont) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
+    row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
+    double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
+    int done;
+    if (!cont) discrete_env_step(env_id, root, pick, ns, &r, &done);
+    else pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, sn, pact, ns, &r, &done);
+    double ret = sp.ret[tree] + r;
+    int t = sp.t[tree] + 1;
+    if (done || t >= sp.max_len) {
+        sp.fsum[tree] = sp.fsum[tree] + ret;
+        sp.fcnt[tree] += 1;
+        ret = 0.0;
+        t = 0;
+        int ep = sp.episode[tree] + 1;
+        sp.episode[tree] = ep;
+        azg_reset_state(P.seed, gtree, (unsigned)ep, azg_reset_kind(env_id), ns);
+        sp.carry[tree] = 0;
+    } else {
+        sp.carry[tree] = (!cont && (pflags & FLAG_EXPANDED)) ? pnode_n : 0;
+    }
+    sp.ret[tree] = ret;
+    sp.t[tree] = t;
+    for (int k = 0; k < S; ++k) sp.roots[(size_t)tree * S + k] = ns[k];
+}
+
+// Roots with more than 16 children (global trees of long continuous searches): one thread per game.
 __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPlay sp, int Kmax, int v_target, int env_id, int S_obs) {
     __shared__ RootKids s_kids[RK_THREADS];
     int tree = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,11 +241,11 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
         row[S_obs + 2 * K + a] = k >= 0 ? (float)h.Q : 0.0f;
         if (k >= 0) {
             if (a == 0 || h.Q > qmax) qmax = h.Q;
-            if (!cont) onp += ((double)h.edge_n / (double)tot) * h.Q;
+            if (!cont && v_target == AZG_VT_ON_POLICY) onp += ((double)h.edge_n / (double)tot) * h.Q;
             if (a == 0 || h.edge_n > cmax) { cmax = h.edge_n; amax = a; }
         }
     }
-    if (cont)
+    if (cont && v_target == AZG_VT_ON_POLICY)
         for (int a = 0; a < nc; ++a)
             for (int b = 0; b < nc; ++b) onp += ((double)rv.rec(b).edge_n / (double)tot) * rv.rec(a).Q;
     row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);

@@ -889,7 +889,10 @@ int azg_selfplay_step(azg_engine* e) {
     sp.rows = e->d_sp_rows + (size_t)slot * e->cfg.n_trees * e->sp_row;
     sp.roots = e->d_roots; sp.carry = e->d_carry;
     const int B = e->cfg.n_trees;
-    hipLaunchKernelGGL(selfplay_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
+    if (e->Kmax <= 16)
+        hipLaunchKernelGGL(selfplay_kernel16, dim3((B + SP_TREES - 1) / SP_TREES), dim3(16 * SP_TREES), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
+    else
+        hipLaunchKernelGGL(selfplay_kernel, dim3((B + RK_THREADS - 1) / RK_THREADS), dim3(RK_THREADS), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
     HIPCHK(e, hipGetLastError());
     e->sp_total += 1;
     e->sp_step_idx += 1;
