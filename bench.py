@@ -299,9 +299,8 @@ def main():
             eng.search_resident()      # the whole search: one launch
             eng.results_resident()     # return_results of every tree: device buffers written by the search kernel's epilogue, no copy
         eng.sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0          # this rank's K steps (the MAX over ranks is taken below) ...
-        barrier()                                   # ... bracketed by a barrier + device sync on both sides
+        barrier()
+        elapsed = time.perf_counter() - t0
         kmed, kmean = time_search(eng, min(args.steps, 10), 0)   # separate pass: the event reads would serialise the timed loop
         res = eng.results()
         assert (res["counts"].sum(1) == N_SIMS).all()
@@ -371,14 +370,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         run(args.steps, True)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0          # this rank's K steps (MAX over ranks below), barrier + device sync on both sides
+        barrier()
+        elapsed = time.perf_counter() - t0
         barrier()
         t1 = time.perf_counter()
         run(args.steps, False)
-        torch.cuda.synchronize()
-        plain = time.perf_counter() - t1
         barrier()
+        plain = time.perf_counter() - t1
         if verify["gathers"]:
             counts = gathered[:, 3 + eng.kmax:3 + 2 * eng.kmax].sum(1)
             assert bool((counts == N_SIMS).all()), "a gathered replay row does not hold n_sims visits"
