@@ -764,7 +764,8 @@ int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1;
 // diagnostic: the form the last search ran in (engine_host.h: kernel_form)
 int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
-// head, waves, tree groups -- see search_kernel.cuh / team.cuh); returns the length written
+// head, waves, tree groups; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
+// the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
     const int env = e->cfg.mode == AZG_MODE_DISCRETE ? 0 : 2;   // (ENV = 0: the discrete family, ENV = 2: both Pendulum versions)
@@ -774,8 +775,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
         case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2:
-            if (e->team_minb <= 2) w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d>", env, e->HP, gmm, e->tree_lds);
-            else w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb);
+            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb);
             break;
         default: w = snprintf(buf, n, "(no search yet)");
     }
