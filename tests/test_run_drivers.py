@@ -77,6 +77,26 @@ def test_device_selfplay_and_training_round(backend):
     assert rows2.shape[0] == 16 and sp.mean_finished_return() < 0
 
 
+def test_device_selfplay_with_three_actions(backend):
+    """MountainCar-v0 (three actions) through the device-resident self-play driver and one A0C training round."""
+    from alphazero_gym_amd.agent.agents import DiscreteAgent
+    torch.manual_seed(1)
+    pol = dict(_target_="alphazero_gym_amd.network.policies.make_policy", representation_dim=2, action_dim=1, distribution="discrete",
+               hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=3)
+    mcts = dict(_target_="alphazero_gym_amd.search.mcts.MCTSDiscrete", num_actions=3, n_rollouts=12, c_uct=1.5, gamma=0.99, epsilon=0,
+                V_target_policy="off_policy", device="cpu", root_state=None)
+    ag = DiscreteAgent(policy_cfg=pol, mcts_cfg=mcts, loss_cfg=run.LOSS_TUNED, optimizer_cfg=run.RMSPROP, final_selection="max_visits",
+                       temperature=1.0, train_epochs=1, grad_clip=0, device="cpu")
+    sp = run.DeviceSelfPlay(ag.nn, game="MountainCar-v0", n_games=6, n_rollouts=12, c_uct=1.5, gamma=0.99, max_episode_length=7, capacity_steps=8)
+    rows = sp.collect(8)
+    assert rows.shape == (48, 2 + 3 * 3 + 1)
+    counts = rows[:, 2 + 3:2 + 6]
+    assert bool((counts.sum(1) == 12).all())
+    assert abs(sp.mean_finished_return() + 7.0) < 1e-9        # reward -1 per step, episodes cut at 7 steps
+    info = run.train_on_rows(ag, rows, 2, 3, batch_size=16)
+    assert np.isfinite(info["loss"])
+
+
 @pytest.mark.gpu
 def test_selfplay_training_learns_pendulum_on_the_gpu():
     """End to end on the device (examples/selfplay_train.py): 512 Pendulum games, 50-sim searches, the reference's A0C loss.
