@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
 from alphazero_gym_amd.envs import CartPoleEnv, MountainCarEnv, PendulumEnv
@@ -130,3 +131,27 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in src and "libazg_oracle" not in src and "azo_" not in src.replace('prefix ``azo_``', ""), f
+
+
+def _build_c_demo(tmp_path):
+    """examples/c_abi_demo.c against include/azgym.h and libazgym_hip.so with plain gcc (C11): the header is C, the boundary needs
+    neither Python nor torch."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "c_abi_demo")
+    libdir = os.path.join(ROOT, "alphazero_gym_amd", "csrc")
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"),
+           "-o", exe, "-L" + libdir, "-lazgym_hip", "-Wl,-rpath," + libdir, "-lm"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return exe
+
+
+def test_c_program_builds_against_the_abi(tmp_path):
+    _build_c_demo(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_program_runs_a_search_through_the_abi(tmp_path):
+    import subprocess
+    p = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "0 trees with a wrong visit total" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
