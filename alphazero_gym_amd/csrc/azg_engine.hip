@@ -142,6 +142,7 @@ void azg_engine_destroy(azg_engine* e) {
     for (void* p : e->dist_allocs) (void)hipFree(p);
     if (e->d_wblob) (void)hipFree(e->d_wblob);
     if (e->d_wmap) (void)hipFree(e->d_wmap);
+    if (e->h_res_block) (void)hipHostFree(e->h_res_block);
     if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
@@ -191,6 +192,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
     e->ls_fork = nullptr;
     e->carry_max = 0;
+    e->h_res_block = nullptr; e->d_res_block = nullptr; e->res_bytes = 0;
     e->d_wblob = nullptr; e->d_wmap = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
     e->d_eval = nullptr; e->eval_floats = 0;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
@@ -250,11 +252,18 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_roots, B * e->S_env, e->dev_allocs));
     CK(dalloc(e, &e->d_carry, B, e->dev_allocs));
     const size_t K = (size_t)e->Kmax;
-    CK(dalloc(e, &e->d_actions, B * K, e->dev_allocs));
-    CK(dalloc(e, &e->d_counts, B * K, e->dev_allocs));
-    CK(dalloc(e, &e->d_Q, B * K, e->dev_allocs));
-    CK(dalloc(e, &e->d_vt, B, e->dev_allocs));
-    CK(dalloc(e, &e->d_nch, B, e->dev_allocs));
+    {
+        // return_results' five arrays in ONE device block (float64 parts first) with a pinned host mirror: azg_results is one
+        // device-to-host copy, not five
+        e->res_bytes = B * K * 8 + B * 8 + B * K * 4 + B * K * 4 + B * 4;
+        char* blk;
+        CK(dalloc(e, &blk, e->res_bytes, e->dev_allocs));
+        e->d_res_block = blk;
+        e->d_Q = (double*)blk; e->d_vt = (double*)(blk + B * K * 8);
+        e->d_actions = (float*)(blk + B * K * 8 + B * 8); e->d_counts = (int*)(blk + B * K * 8 + B * 8 + B * K * 4);
+        e->d_nch = (int*)(blk + B * K * 8 + B * 8 + B * K * 8);
+        HK(hipHostMalloc(&e->h_res_block, e->res_bytes, hipHostMallocDefault));
+    }
     CK(dalloc(e, &e->d_child_n, B * K, e->dev_allocs));
     CK(dalloc(e, &e->d_child_state, B * K * e->S_env, e->dev_allocs));
     CK(dalloc(e, &e->d_rootV, B, e->dev_allocs));
@@ -644,14 +653,19 @@ static int gather_results(azg_engine* e) {
 
 int azg_results(azg_engine* e, float* actions, int32_t* counts, double* Q, double* v_target, int32_t* n_children) {
     if (!e) return AZG_E_INVALID;
-    int rc = gather_results(e);
+    ON_DEVICE(e);
+    int rc = launch_results(e);
     if (rc) return rc;
-    size_t B = e->cfg.n_trees, K = e->Kmax;
-    D2H(actions, e->d_actions, B * K * 4);
-    D2H(counts, e->d_counts, B * K * 4);
-    D2H(Q, e->d_Q, B * K * 8);
-    D2H(v_target, e->d_vt, B * 8);
-    D2H(n_children, e->d_nch, B * 4);
+    const size_t B = e->cfg.n_trees, K = e->Kmax;
+    // one copy of the whole block into pinned memory behind the search (and results) on the engine's stream, then host copies
+    HIPCHK(e, hipMemcpyAsync(e->h_res_block, e->d_res_block, e->res_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const char* h = (const char*)e->h_res_block;
+    if (Q) memcpy(Q, h, B * K * 8);
+    if (v_target) memcpy(v_target, h + B * K * 8, B * 8);
+    if (actions) memcpy(actions, h + B * K * 8 + B * 8, B * K * 4);
+    if (counts) memcpy(counts, h + B * K * 8 + B * 8 + B * K * 4, B * K * 4);
+    if (n_children) memcpy(n_children, h + B * K * 8 + B * 8 + B * K * 8, B * 4);
     return AZG_OK;
 }
 

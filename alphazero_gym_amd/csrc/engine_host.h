@@ -63,6 +63,7 @@ struct azg_engine {
     // results staging
     float* d_actions; int* d_counts; double* d_Q; double* d_vt; int* d_nch; int* d_child_n; double* d_child_state;
     float* d_rootV; float* d_rootdist;
+    char* d_res_block; void* h_res_block; size_t res_bytes;   // d_Q | d_vt | d_actions | d_counts | d_nch in one block + its pinned host mirror
     double* d_roots; int* d_carry;
     uint32_t search_idx;
     int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;   // sp_steps = ReplayBuffer.size in steps
