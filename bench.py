@@ -61,6 +61,9 @@ def profiled_traffic(tag=""):
     for f in reversed(files):
         vals = {}
         for r in csv.DictReader(open(f)):
+            name = r.get("kernel") or r.get("Kernel_Name") or ""
+            if name and not ("search_kernel" in name or "ls_team_kernel" in name):
+                continue                                   # (the summaries of the wide configs also list the small kernels)
             vals[r["counter"]] = float(r["mean_per_launch"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(f, ROOT)
@@ -188,7 +191,7 @@ def tree_walk_bytes(dump, n_actions, n_sims):
     return 16 * L + 16 * C + 56 * L + 92 * E + 40, L, C, E
 
 
-def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, flops_per_sim, note, device_id, hbm_tag=None):
+def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, flops_per_sim, note, device_id, hbm_tag=None, traffic_tag=None):
     import ctypes as C
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
@@ -206,6 +209,10 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, f
            "kernels": [ran], "note": note}
     if ran != expect:
         out["fallback"] = f"expected {expect}; the engine ran {ran} (team-kernel fallbacks: {fallbacks})"
+    if traffic_tag and ran == expect:
+        t, src = profiled_traffic(traffic_tag)
+        out["roofline"]["traffic"] = t
+        out["roofline"]["traffic_source"] = src
     if hbm_tag:
         # the tree-walk-bound config also gets SURVEY 8d's HBM-side figure: declared minimal bytes of the walk / time / HBM peak
         per_sim, L, Cn, E = tree_walk_bytes(eng.dump_tree(), kw.get("num_actions", 2), n_sims)
@@ -420,7 +427,8 @@ def main():
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
                              "ls_team_kernel<2, 1024, false, 1, 4, 2>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
-                             "layer for the team's 32 trees each), hand-offs through global memory", dev),
+                             "layer for the team's 32 trees each), hand-offs through global memory; traffic = L2 misses of the cross-XCD "
+                             "activation hand-offs (DESIGN.md section 3), the weights stay L2-resident", dev, traffic_tag="E"),
                 extra_config("E's network at 2048 trees per GPU", PENDULUM, 2048, 200, 3, [1024] * 4, 2, "elu",
                              "ls_team_kernel<2, 1024, false, 1, 2, 4>",
                              mlp_flops(3, [1024] * 4, 3), "the team kernel's four-workgroups-per-CU form (short staging chunks): while one workgroup of a CU waits "
