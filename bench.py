@@ -70,6 +70,65 @@ def profiled_traffic(tag=""):
     return None, None
 
 
+def traffic_probe(args):
+    """`--traffic-probe` (child of live_traffic below, run under rocprofv3 --pmc): a few searches of the headline shape, nothing else."""
+    from alphazero_gym_amd import _capi, _native
+    from alphazero_gym_amd.synthetic import make_weights
+    eng = _native.HipEngine(n_trees=args.trees, n_sims=N_SIMS, **PENDULUM)
+    eng.set_weights(_capi.make_desc(3, HIDDEN, 2, "elu"), make_weights(34, 3, HIDDEN, 2))
+    eng.upload_roots(eng.synthetic_roots())
+    for _ in range(6):
+        eng.search_resident()
+    eng.sync()
+    eng.close()
+
+
+def live_traffic(trees):
+    """HBM bytes per launch of the search kernel measured NOW: two child runs of this script's --traffic-probe under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one), values in KiB per
+    dispatch, the read side doubled (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM section -- an
+    upper bound for this kernel's narrow reads).  The children are started as ordinary child processes from /tmp with
+    TMPDIR=/tmp; the program after `--` is the interpreter itself.  (bytes, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    # the program after `--` must be the interpreter binary itself (no wrapper script, no launcher that re-execs under the profiler)
+    py = os.path.realpath(sys.executable)
+    try:
+        if open(py, "rb").read(4) != b"\x7fELF":
+            return None, "the interpreter is not an ELF binary"
+    except OSError:
+        return None, "the interpreter binary cannot be read"
+    out = {}
+    work = tempfile.mkdtemp(prefix="azg_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__), "--traffic-probe",
+                   "--trees", str(trees)]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {p.returncode}"
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "search_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if len(vals) < 2:
+                return None, f"no {counter} rows for the search kernel"
+            out[counter] = float(np.mean(vals[1:]))          # (the first launch also pulls the weights and tables in)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, None
+
+
 def physical_cores():
     """Distinct (package, core) pairs; falls back to the logical count."""
     seen = set()
@@ -255,10 +314,14 @@ def main():
     ap.add_argument("--config-d", action="store_true", help="run the N > 1 loop (self-play step + all-gather + weight broadcast) also with one rank: "
                                                             "RCCL with world size 1 on the engine-owned ring")
     ap.add_argument("--verify-gather", action="store_true", help="N > 1 loop: check every gathered block against the rows the previous step wrote (slow)")
+    ap.add_argument("--traffic-probe", action="store_true", help="(internal) a few searches for the PMC passes of live_traffic()")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: take roofline.traffic from the committed profile instead of measuring it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the config B / E lines")
     args = ap.parse_args()
 
+    if args.traffic_probe:
+        return traffic_probe(args)
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.config_d):
         spawn(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -434,6 +497,15 @@ def main():
                              mlp_flops(3, [1024] * 4, 3), "the team kernel's four-workgroups-per-CU form (short staging chunks): while one workgroup of a CU waits "
                              "at a hand-off or walks its trees the other three keep the matrix pipe busy", dev),
             ]
+        traffic, traffic_note = None, "not measured (N > 1 loop)"
+        if not config_d:
+            if not args.no_live_traffic:
+                traffic, why = live_traffic(B)
+                traffic_note = ("measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) over 5 launches of this kernel, "
+                                "2 x FETCH + WRITE") if traffic is not None else f"live PMC passes unavailable ({why})"
+            if traffic is None and B == N_TREES:
+                traffic, src = profiled_traffic()
+                traffic_note += f"; from the committed passes ({src})"
         out = {
             "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -441,13 +513,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "trees_per_gpu": B, "n_sims": N_SIMS, "parallelism": parallelism},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": profiled_traffic()[0] if (B == N_TREES and not config_d) else None,
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname + " (template arguments: ENV 2 = Pendulum, HP = padded hidden width, NREG = hidden->hidden layers held in "
                                    "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup, 16-tree groups per workgroup)",
                          "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
-                                 "the committed rocprofv3 PMC passes (" + str(profiled_traffic()[1]) + "), not measured in this run; `value` is wall "
+                                 "rocprofv3 PMC passes (see traffic_note); `value` is wall "
                                  "time over K steps of search + return_results (written by the same launch's epilogue) with everything resident in HBM, the PCIe-inclusive "
                                  "rate is extra.pcie_inclusive"},
             "extra": extra,
