@@ -54,7 +54,7 @@ typedef struct azg_config {
     int32_t mode;          /* AZG_MODE_* */
     int32_t n_trees;       /* B: independent trees searched by one azg_search call */
     int32_t n_sims;        /* n_rollouts */
-    int32_t num_actions;   /* discrete only */
+    int32_t num_actions;   /* discrete only: the env's own action count (CartPole 2, MountainCar 3) */
     int32_t v_target;      /* AZG_VT_* */
     int32_t tree_id_base;  /* global id of local tree 0 (multi-GPU sharding; keys the RNG streams) */
     int32_t tie_break;     /* AZG_TIE_* : what helpers.argmax (helpers.py:30-52) does with exactly equal scores */
