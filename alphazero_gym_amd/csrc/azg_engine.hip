@@ -180,6 +180,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.force_global_tree = env_digit("AZG_FORCE_GLOBAL_TREE", 0) == 1;
     e->opt.waves = env_digit("AZG_WAVES", 0);
     e->opt.groups = env_digit("AZG_GROUPS", 0);
+    { const char* v = getenv("AZG_TILE_TREES"); const int t = v ? atoi(v) : 0; e->opt.tile_trees = (t == 16 || t == 8 || t == 4) ? t : 0; }
     e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
     e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
@@ -228,7 +229,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->dyn_lds = 0;
     DeviceScope scope(cfg->device_id);
     if (!scope.ok) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
-    e->waves = 4; e->groups = 1; e->n_cus = 256;
+    e->waves = 4; e->groups = 1; e->tile_trees = 16; e->n_cus = 256;
     (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
 #define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
@@ -270,7 +271,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
     {
         unsigned long long* st;
-        CK(dalloc(e, &st, ((B + TREES_PER_WG - 1) / TREES_PER_WG) * 8 * 16, e->dev_allocs));   // (diagnostic builds: up to 8 waves per 16-tree group)
+        CK(dalloc(e, &st, ((B + 3) / 4) * 4 * 16, e->dev_allocs));   // (diagnostic builds: one row per wave; at most 4 waves per 4 trees)
         e->P.stamps = st;
     }
     std::vector<double> sq(e->tab_n);
@@ -778,7 +779,7 @@ int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1;
 // diagnostic: the form the last search ran in (engine_host.h: kernel_form)
 int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
-// head, waves, tree groups; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
+// head, waves, tree groups, trees per group; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
 // the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
@@ -786,7 +787,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
     int w = 0;
     switch (e->kernel_form) {
-        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups); break;
+        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2:
             w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb);
@@ -799,7 +800,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
-    size_t rows = (size_t)((e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG) * 8;
+    size_t rows = (size_t)((e->cfg.n_trees + 3) / 4) * 4;
     if (rows > max_rows) rows = max_rows;
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -12,9 +12,9 @@
 
 // One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
 // Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
-template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16>
 static hipError_t launch_g(azg_engine* e) {
-    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>;
+    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG, NT>;
     static std::atomic<int> static_lds_cache{-1};   // per kernel variant; engines of several host threads may race to fill it
     int static_lds = static_lds_cache.load(std::memory_order_relaxed);
     if (static_lds < 0) {
@@ -28,34 +28,34 @@ static hipError_t launch_g(azg_engine* e) {
     // cost a second resident workgroup: a batch with more workgroups than CUs runs two of them side by side on a CU if their LDS
     // allows it, which is worth far more (CartPole, 8192 trees, 2x128: 0.62 ms per search against 0.94 ms)
     constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
-    LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 1);
-    const long n_wg = (e->cfg.n_trees + 16 * NG - 1) / (16 * NG);
+    LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 1, NT);
+    const long n_wg = (e->cfg.n_trees + NT * NG - 1) / (NT * NG);
     const size_t with_state = L.total + (size_t)static_lds;
-    const size_t without = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 0).total + (size_t)static_lds;
+    const size_t without = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 0, NT).total + (size_t)static_lds;
     const bool costs_a_neighbour = n_wg > e->n_cus && 2 * without <= 160 * 1024 && 2 * with_state > 160 * 1024;
     e->P.lds_state = (!CONT && TLDS != TS_GLOBAL && with_state <= 160 * 1024 && !costs_a_neighbour && !getenv("AZG_NO_LDS_STATE")) ? 1 : 0;
-    if (!e->P.lds_state) L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 0);
+    if (!e->P.lds_state) L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 0, NT);
     if (L.total + (size_t)static_lds > 160 * 1024) return hipErrorInvalidConfiguration;
     if (L.total > 48 * 1024) {
         hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (rc != hipSuccess) return rc;
     }
-    const int tpw = 16 * NG;
+    const int tpw = NT * NG;
     dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
     e->tree_lds = TLDS;
     e->dyn_lds = L.total;
-    e->waves = NW; e->groups = NG;
+    e->waves = NW; e->groups = NG; e->tile_trees = NT;
     e->kernel_form = 0;
     hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
     return hipGetLastError();
 }
 
-template <int ENV, int HP, int NREG, int TLDS, int NW, int NG>
+template <int ENV, int HP, int NREG, int TLDS, int NW, int NG, int NT = 16>
 static hipError_t launch_t(azg_engine* e) {
-    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4) {
+    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4 && NT == 16) {
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
     }
-    return launch_g<ENV, HP, NREG, TLDS, false, NW, NG>(e);
+    return launch_g<ENV, HP, NREG, TLDS, false, NW, NG, NT>(e);
 }
 
 // Variant choice.  Trees live in LDS when they fit (8-bit record ids, 16-bit counts, <= 16 children per node, the CU's 160 KB).
@@ -86,6 +86,20 @@ static hipError_t launch(azg_engine* e) {
             hipError_t rc = hipErrorInvalidConfiguration;
             if (two) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 2>(e);
             if (rc == hipErrorInvalidConfiguration) rc = launch_t<ENV, HP, NREG, TS_LDS8, 8, 1>(e);
+            if (rc != hipErrorInvalidConfiguration) return rc;
+        }
+    }
+    // Half-filled tiles (small register-resident networks, LDS trees): a batch that cannot give every CU two 16-tree workgroups is
+    // cut into 8-tree workgroups -- two per CU at 4096 trees on 256 CUs -- or, when even those are fewer than two per CU, 4-tree
+    // ones.  AZG_TILE_TREES=16|8|4 forces a shape (tests).
+    if constexpr (HP <= 128 && NREG == 1) {
+        if (ts == TS_LDS8 && e->P.ncomp < 2) {
+            const long g16 = (e->cfg.n_trees + 15) / 16, g8 = (e->cfg.n_trees + 7) / 8;
+            int nt = g16 >= 2L * e->n_cus ? 16 : (g8 >= 2L * e->n_cus ? 8 : 4);
+            if (e->opt.tile_trees) nt = e->opt.tile_trees;
+            hipError_t rc = hipErrorInvalidConfiguration;
+            if (nt == 4) rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1, 4>(e);
+            if (nt == 8 || (nt == 4 && rc == hipErrorInvalidConfiguration)) rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1, 8>(e);
             if (rc != hipErrorInvalidConfiguration) return rc;
         }
     }

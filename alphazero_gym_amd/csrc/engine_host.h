@@ -16,6 +16,7 @@ struct EngineOptions {
     int force_global_tree;     // AZG_FORCE_GLOBAL_TREE=1: trees in global memory instead of LDS
     int waves;                 // AZG_WAVES=4|8 (0: automatic)
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
+    int tile_trees;            // AZG_TILE_TREES=16|8|4: trees per 16-column MFMA tile of the small-network kernels (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
     // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
     int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of
@@ -46,7 +47,8 @@ struct azg_engine {
     int S_env, S_obs, Kmax, Kp, R, nd, tab_n;
     int mlp_ready, HP, n_hidden, n_out, act, nreg;
     int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
-    int waves, groups, n_cus; // waves / 16-tree groups per workgroup of the last launch; compute units of the device
+    int waves, groups, n_cus; // waves / tree groups per workgroup of the last launch; compute units of the device
+    int tile_trees;          // trees per group (= per 16-column MFMA tile) of the last launch: 16, or 8 / 4 (half-filled tiles)
     size_t dyn_lds;          // dynamic LDS bytes per workgroup
     float ls_min, ls_max;
     hipStream_t stream;

@@ -133,7 +133,8 @@ __device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4
 // float4 = the D registers of each 16x16 output tile as they stand); a layer's output stays in registers until the next layer
 // publishes it, and the last layer's output feeds the head MFMAs directly.
 // (WR: WRegs<HP, NREG, NW>, or a look-alike that keeps some of the small operands elsewhere -- tools/probes/pair's server)
-template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>>
+// NT: trees per group (16, or fewer: the remaining columns of the tile are fed zeros); obsT is then [4][NT*NG].
+template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>, int NT = 16>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, const float* obsT, f32x4* actA, f32x4* actB,
                                             f32x4* parts, float* s_ln, int wave, int lane
 #ifdef AZG_STAMPS
@@ -150,7 +151,9 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
     // layer 0: K = in_dim <= 4 -> one k-step
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        float b = obsT[(lane >> 4) * (16 * NG) + g * 16 + (lane & 15)];
+        float b;
+        if constexpr (NT == 16) b = obsT[(lane >> 4) * (16 * NG) + g * 16 + (lane & 15)];
+        else b = (lane & 15) < NT ? obsT[(lane >> 4) * (NT * NG) + g * NT + (lane & 15)] : 0.0f;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             if constexpr (HP <= 256) {

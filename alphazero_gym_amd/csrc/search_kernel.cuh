@@ -4,6 +4,9 @@
 //   NW = 8, NG = 1: two waves per SIMD, 2 trees per wave: half the activation math and less tree-walk divergence per wave;
 //   NW = 8, NG = 2: two waves per SIMD, 32 trees: one wave's tree walk / activation math overlaps the other's MFMAs
 //                   (pays off when the batch has more 16-tree groups than the device has CUs).
+// NT < 16 ("half-filled tiles"): a group holds only NT = 8 or 4 trees, the other columns of its MFMA tile carry zeros.  A batch that
+// would leave every CU with ONE 16-tree workgroup (4096 trees on 256 CUs) becomes two or four workgroups per CU, whose serial
+// tree-walk chains then overlap; the matrix pipe is nearly idle in those shapes (small networks), so the empty columns are free.
 #pragma once
 #include "records.h"
 #include "env.cuh"
@@ -21,7 +24,7 @@ struct LdsLayout {
     size_t total;
 };
 // lds_state (discrete LDS trees): n_sims + 1 slots of 4 doubles per tree for the env states of the expanded nodes
-__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, int tlds, int lds_state = 0) {
+__host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, int NG, int nbuf, int R, bool cont, int tlds, int lds_state = 0, int NT = 16) {
     LdsLayout L;
     L.act_off = ((size_t)tab_n * 8 + (size_t)(n_sims + 2) * 2 + 15) / 16 * 16;
     L.tree_off = L.act_off + (size_t)nbuf * NG * HP * 64;
@@ -29,16 +32,17 @@ __host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, i
     L.per_tree = (L.per_tree + 15) / 16 * 16;
     L.state_off = 0;
     if (lds_state && !cont && tlds != TS_GLOBAL) { L.state_off = L.per_tree; L.per_tree += (size_t)(n_sims + 1) * 32; }
-    L.total = L.tree_off + (tlds != TS_GLOBAL ? L.per_tree * 16 * NG : 0);
+    L.total = L.tree_off + (tlds != TS_GLOBAL ? L.per_tree * NT * NG : 0);
     return L;
 }
 // activation buffers a kernel variant needs: one when a single register-resident hidden layer reads what layer 0 wrote
 __host__ __device__ constexpr int act_buffers(int NREG) { return NREG == 1 ? 1 : 2; }
 
-template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG>
-__global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16>
+__global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
-    constexpr int TPW = 16 * NG;        // trees per workgroup
+    static_assert(NT == 16 || (NG == 1 && NW == 4 && (NT == 8 || NT == 4)), "half-filled tiles: one group, four waves");
+    constexpr int TPW = NT * NG;        // trees per workgroup
     constexpr int TPV = TPW / NW;       // trees per wave (16 lanes each; the wave's other lanes sit the tree phases out)
     typedef typename TreeStore<TLDS>::Rec Rec;
     constexpr int NCH = head_chunks<HP>();   // partial head sums per tree
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
     // packed two fields to a register, and the path's rewards / returns are fetched after the network phase instead of during
     // the descent.  With one wave per SIMD (NW = 4: 512 registers) everything stays in registers (measured faster there).
     constexpr bool LEAN = (NW == 8);
-    const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS, P.lds_state);
+    const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS, P.lds_state, NT);
     double* s_sqrt = s_dyn;
     unsigned short* s_pw = (unsigned short*)(s_dyn + P.tab_n);   // widening thresholds, clamped (a node has < 32768 children)
     f32x4* s_actA = (f32x4*)((char*)s_dyn + L.act_off);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
             c.ts.child = P.child + c.tb * P.Kp;
             c.ts.prior = P.prior + c.tb;
         }
-        c.my_parts = s_parts + (c.tl >> 4) * NCH * PSTR;   // the head partials of this tree's group
+        c.my_parts = s_parts + (c.tl / NT) * NCH * PSTR;   // the head partials of this tree's group
         return c;
     };
     Ctx cx = make_ctx(tid);
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
             asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3));
         }
 #ifdef AZG_STAMPS
-        mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
-        mlp_forward<HP, NREG, NW, NG, PSTR>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
         if constexpr (LEAN) {
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, 1) void search_kernel(KParams P) {
             if (cx.live && sim >= 0 && st.my_depth >= 1) { st.pr = cx.cold[st.pid].r; st.pW = cx.edge_W[st.pid]; }
         }
         // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl & 15, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
         if (sim == P.n_sims - 1) break;
         __threadfence_block();
         STAMP(t_d);

@@ -70,12 +70,20 @@ def profiled_traffic(tag=""):
     return None, None
 
 
+PROBE_SHAPES = {   # --probe-config: (engine kwargs, n_sims, in_dim, hidden, activation)
+    "C": (PENDULUM, N_SIMS, 3, HIDDEN, "elu"),
+    "B": (CARTPOLE, 100, 4, [128, 128], "relu"),
+    "E": (PENDULUM, N_SIMS, 3, [1024] * 4, "elu"),
+}
+
+
 def traffic_probe(args):
-    """`--traffic-probe` (child of live_traffic below, run under rocprofv3 --pmc): a few searches of the headline shape, nothing else."""
+    """`--traffic-probe` (child of live_traffic below, run under rocprofv3 --pmc): a few searches of one shape, nothing else."""
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
-    eng = _native.HipEngine(n_trees=args.trees, n_sims=N_SIMS, **PENDULUM)
-    eng.set_weights(_capi.make_desc(3, HIDDEN, 2, "elu"), make_weights(34, 3, HIDDEN, 2))
+    kw, n_sims, in_dim, hidden, act = PROBE_SHAPES[args.probe_config]
+    eng = _native.HipEngine(n_trees=args.trees, n_sims=n_sims, **kw)
+    eng.set_weights(_capi.make_desc(in_dim, hidden, 2, act), make_weights(34, in_dim, hidden, 2))
     eng.upload_roots(eng.synthetic_roots())
     for _ in range(6):
         eng.search_resident()
@@ -83,7 +91,23 @@ def traffic_probe(args):
     eng.close()
 
 
-def live_traffic(trees):
+def under_profiler():
+    """True when this process already runs under rocprofv3 / rocprofiler-sdk (its tool library is preloaded into every child):
+    a nested rocprofv3 would then re-exec a process whose GPU runtime is already initialised."""
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return True
+    return any(k.startswith("ROCPROF") for k in os.environ)
+
+
+def clean_child_env():
+    """The parent's environment without anything a profiler put there (LD_PRELOAD, ROCP_*, ROCPROF*): no hop in front of the
+    final interpreter of a child run carries a tool library."""
+    env = {k: v for k, v in os.environ.items() if not (k == "LD_PRELOAD" or k.startswith("ROCP_") or k.startswith("ROCPROF"))}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
+def live_traffic(trees, config="C", kernel="search_kernel"):
     """HBM bytes per launch of the search kernel measured NOW: two child runs of this script's --traffic-probe under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one), values in KiB per
     dispatch, the read side doubled (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM section -- an
@@ -93,6 +117,8 @@ def live_traffic(trees):
     import glob
     import shutil
     import tempfile
+    if under_profiler():
+        return None, "already under a profiler"
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
@@ -109,9 +135,9 @@ def live_traffic(trees):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__), "--traffic-probe",
-                   "--trees", str(trees)]
+                   "--trees", str(trees), "--probe-config", config]
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+                p = subprocess.run(cmd, cwd="/tmp", env=clean_child_env(), capture_output=True, text=True, timeout=240)
             except subprocess.TimeoutExpired:
                 return None, f"rocprofv3 --pmc {counter} timed out"
             if p.returncode != 0:
@@ -119,10 +145,10 @@ def live_traffic(trees):
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "search_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
                         vals.append(float(r["Counter_Value"]))
             if len(vals) < 2:
-                return None, f"no {counter} rows for the search kernel"
+                return None, f"no {counter} rows for {kernel}"
             out[counter] = float(np.mean(vals[1:]))          # (the first launch also pulls the weights and tables in)
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -160,7 +186,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline():
+def cpu_baseline(short=False):
     """CPU lines next to the GPU number, each on a bounded sample of the same workload:
       * the C oracle (scalar port of the per-tree algorithm, OpenMP over trees, trees allocated by their worker thread) on one
         thread and on one thread per physical core;
@@ -197,20 +223,22 @@ def cpu_baseline():
 
     r1, _, _ = oracle_rate(1, 16)                                  # ~0.3 s: sizes the samples
     n1 = int(max(16, min(N_TREES, r1 * 2.0 / N_SIMS)))
-    r1, dt1, reps1 = oracle_rate(1, n1, 4.0)
+    r1, dt1, reps1 = oracle_rate(1, n1, 2.0 if short else 4.0)
     nall = int(max(cores, min(N_TREES, r1 * cores * 2.0 / N_SIMS)))
-    rall, dtall, repsall = oracle_rate(cores, nall, 8.0)
+    rall, dtall, repsall = oracle_rate(cores, nall, 4.0 if short else 8.0)
+    out = {"value": rall, "unit": "sims/s", "cores": cores, "kind": "port",
+           "sample": f"{repsall} searches of {nall} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle, OpenMP over trees on "
+                     f"{cores} threads (physical cores {physical_cores()}, usable CPUs {usable_cpus()}, logical CPUs {os.cpu_count()}), {dtall:.1f} s",
+           "single_thread": {"value": r1, "unit": "sims/s", "cores": 1, "sample": f"{reps1} searches of {n1} trees x {N_SIMS} sims, {dt1:.1f} s"}}
+    if short:   # (N > 1 runs: the other ranks are waiting)
+        return out
     procs = min(cores, 64)
-    t0 = time.perf_counter()
-    rpy = pytree.throughput("pendulum", n_rollouts=N_SIMS, hidden=HIDDEN, processes=procs, trees_per_process=8)
-    dtpy = time.perf_counter() - t0
-    return {"value": rall, "unit": "sims/s", "cores": cores, "kind": "port",
-            "sample": f"{repsall} searches of {nall} of {N_TREES} trees x {N_SIMS} sims, same seeds/weights, C oracle, OpenMP over trees on "
-                      f"{cores} threads (physical cores {physical_cores()}, usable CPUs {usable_cpus()}, logical CPUs {os.cpu_count()}), {dtall:.1f} s",
-            "single_thread": {"value": r1, "unit": "sims/s", "cores": 1, "sample": f"{reps1} searches of {n1} trees x {N_SIMS} sims, {dt1:.1f} s"},
-            "python_object_tree": {"value": rpy, "unit": "sims/s", "cores": procs, "kind": "port",
-                                   "sample": f"{procs} processes x 8 trees x {N_SIMS} sims, 1 torch thread each, oracle/pytree.py "
-                                             f"(the reference's cost structure: batch-1 torch forwards, env replay, numpy UCT), {dtpy:.1f} s incl. start-up"}}
+    rpy, simspy, dtpy = pytree.throughput("pendulum", n_rollouts=N_SIMS, hidden=HIDDEN, processes=procs, trees_per_process=8, seconds=6.0, detail=True)
+    out["python_object_tree"] = {"value": rpy, "unit": "sims/s", "cores": procs, "kind": "port",
+                                 "sample": f"{procs} processes x 1 torch thread, whole searches of {N_SIMS} sims for {dtpy:.1f} s each ({simspy} simulations in all, "
+                                           "start-up outside the clock), oracle/pytree.py (the reference's cost structure: batch-1 torch forwards, env replay "
+                                           "from the root, numpy UCT)"}
+    return out
 
 
 def time_search(eng, steps, warmup):
@@ -235,6 +263,7 @@ def kernel_name(eng):
 
 
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md)
+B_KERNEL = "search_kernel<0, 128, 1, 1, false, 4, 1, 8>"   # what config B is expected to run as (the engine reports what it did run)
 
 
 def tree_walk_bytes(dump, n_actions, n_sims):
@@ -250,7 +279,49 @@ def tree_walk_bytes(dump, n_actions, n_sims):
     return 16 * L + 16 * C + 56 * L + 92 * E + 40, L, C, E
 
 
-def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, flops_per_sim, note, device_id, hbm_tag=None, traffic_tag=None):
+def tree_walk_bytes_continuous(dump, n_sims, c_pw, kappa):
+    """The same declared traffic for a progressive-widening search (no priors: 12 B per scanned child): L from the edge counts, E
+    from the expanded records, C = children scored, reconstructed exactly from the nodes' visit counts: a node's v-th visit either
+    widens it (states.py:271-275: ceil(c_pw (v+1)^kappa) > K) or scores its K children (mcts.py:728-741), so the number of
+    children a node has scored so far is a function of its visit count alone (the root starts with the child of mcts.py:673)."""
+    import math
+    B = dump["n_records"].shape[0]
+    sims = float(B * n_sims)
+    scored = np.zeros((2, n_sims + 2), np.float64)     # [is_root][visits] -> children scored over those visits
+    kids = np.zeros((2, n_sims + 2), np.int64)
+    for root in (0, 1):
+        K, Cacc = root, 0
+        for v in range(n_sims + 1):
+            scored[root, v], kids[root, v] = Cacc, K
+            if math.ceil(c_pw * (min(v, n_sims + 1) + 1) ** kappa) > K:
+                K += 1
+            else:
+                Cacc += K
+        scored[root, n_sims + 1], kids[root, n_sims + 1] = Cacc, K
+    nn = np.minimum(dump["node_n"], n_sims + 1)
+    is_root = np.zeros_like(nn); is_root[:, 0] = 1
+    valid = np.arange(nn.shape[1])[None, :] < dump["n_records"][:, None]
+    Cn = float((scored[is_root, nn] * valid).sum()) / sims
+    L = float((dump["edge_n"] * valid).sum()) / sims
+    E = float((((dump["node_flags"] & 1) != 0) & valid).sum() - B) / sims
+    return 16 * L + 12 * Cn + 56 * L + 92 * E + 40, L, Cn, E
+
+
+def hbm_block(per_sim, L, Cn, E, trees, n_sims, ms, traffic, traffic_note):
+    gbs = trees * n_sims * per_sim / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+            "traffic_frac_of_peak": (traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
+            "bytes_per_sim": per_sim, "levels_per_sim": L, "children_per_sim": Cn, "expansions_per_sim": E,
+            "note": "the tree walk against the HBM roofline (SURVEY 8d): achieved = algorithmic bytes (16L + 12C [+ 4C priors] + 56L + 92E + 40 "
+                    "per simulation, L / C / E counted from the searched trees) x simulations / launch time; traffic = HBM bytes per "
+                    "launch, " + traffic_note + ".  The hot records live in LDS for the whole search, so the counter traffic is below "
+                    "the algorithmic bytes and both are far below the HBM peak: the walk is bound by dependent-access latency"}
+
+
+def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, flops_per_sim, note, device_id, hbm=False, live=None):
+    """One more configuration timed like the headline.  flops_per_sim None: evaluations per simulation counted from the trees x
+    the network's FLOP.  hbm: add SURVEY 8d's HBM-side block.  live = (--probe-config tag, kernel name): measure HBM traffic with two
+    rocprofv3 --pmc child passes (falls back to the committed profile)."""
     import ctypes as C
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
@@ -262,28 +333,29 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, f
     assert (res["counts"].sum(1) == n_sims).all()
     ran = kernel_name(eng)
     fallbacks = _native.lib().azg_debug_team_fallbacks(C.c_void_p(eng._h.value))
+    walk = None
+    if hbm or flops_per_sim is None:
+        walk = tree_walk_bytes(eng.dump_tree(), kw.get("num_actions", 2), n_sims)
+    if flops_per_sim is None:
+        flops_per_sim = walk[3] * mlp_flops(in_dim, hidden, 1 + n_dist)   # (E evaluations per simulation: traces that end in a terminal node need none)
+    eng.close()
     ach = trees * n_sims * flops_per_sim / (med * 1e-3) / 1e12
     out = {"config": name, "ms_per_search": med, "ms_mean": mean, "sims_per_s": trees * n_sims / (med * 1e-3), "trees": trees, "n_sims": n_sims,
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS},
            "kernels": [ran], "note": note}
     if ran != expect:
         out["fallback"] = f"expected {expect}; the engine ran {ran} (team-kernel fallbacks: {fallbacks})"
-    if traffic_tag and ran == expect:
-        t, src = profiled_traffic(traffic_tag)
-        out["roofline"]["traffic"] = t
-        out["roofline"]["traffic_source"] = src
-    if hbm_tag:
-        # the tree-walk-bound config also gets SURVEY 8d's HBM-side figure: declared minimal bytes of the walk / time / HBM peak
-        per_sim, L, Cn, E = tree_walk_bytes(eng.dump_tree(), kw.get("num_actions", 2), n_sims)
-        gbs = trees * n_sims * per_sim / (med * 1e-3) / 1e9
-        traffic, src = profiled_traffic(hbm_tag)
-        out["roofline_hbm"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                               "traffic": traffic, "bytes_per_sim": per_sim, "levels_per_sim": L, "children_per_sim": Cn,
-                               "expansions_per_sim": E,
-                               "note": "algorithmic bytes = 16L + 12C + 4C + 56L + 92E + 40 per simulation (SURVEY 8d) with L, C, E counted "
-                                       "from the searched trees; traffic = HBM bytes per launch from the committed PMC passes"
-                                       + (f" ({src})" if src else " (none committed yet)")}
-    eng.close()
+    traffic, tnote = None, "not measured"
+    if live and ran == expect:
+        traffic, why = live_traffic(trees, live[0], live[1])
+        tnote = "measured in this run (two rocprofv3 --pmc child passes, 2 x FETCH_SIZE + WRITE_SIZE)"
+        if traffic is None:
+            traffic, src = profiled_traffic(live[0])
+            tnote = f"live PMC passes unavailable ({why}); from the committed passes ({src})"
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_note"] = tnote
+    if hbm:
+        out["roofline_hbm"] = hbm_block(*walk, trees, n_sims, med, traffic, tnote)
     return out
 
 
@@ -294,8 +366,9 @@ def spawn(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--gather-every", str(args.gather_every),
-           "--backend", args.backend]
-    for flag, on in (("--same-device", args.same_device), ("--config-d", args.config_d), ("--verify-gather", args.verify_gather)):
+           "--backend", args.backend, "--dist-timeout", str(args.dist_timeout)]
+    for flag, on in (("--same-device", args.same_device), ("--config-d", args.config_d), ("--verify-gather", args.verify_gather),
+                     ("--no-cpu-baseline", args.no_cpu_baseline)):
         if on:
             cmd.append(flag)
     sys.exit(subprocess.call(cmd))
@@ -315,8 +388,11 @@ def main():
                                                             "RCCL with world size 1 on the engine-owned ring")
     ap.add_argument("--verify-gather", action="store_true", help="N > 1 loop: check every gathered block against the rows the previous step wrote (slow)")
     ap.add_argument("--traffic-probe", action="store_true", help="(internal) a few searches for the PMC passes of live_traffic()")
+    ap.add_argument("--probe-config", default="C", choices=sorted(PROBE_SHAPES), help="(internal) the shape --traffic-probe runs")
     ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: take roofline.traffic from the committed profile instead of measuring it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-timeout", type=float, default=300.0, help="N > 1: seconds before a rendezvous / collective that does not complete "
+                                                                      "(a dead rank) fails the run")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the config B / E lines")
     args = ap.parse_args()
 
@@ -336,10 +412,15 @@ def main():
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         torch.cuda.set_device(dev)
+        # bounded rendezvous and collectives: a rank that never shows up, or dies, makes the others fail (RCCL's watchdog aborts
+        # the process when a collective exceeds the timeout; torch.distributed.run then tears the job down) -- the bench exits
+        # non-zero instead of hanging
+        import datetime
+        limit = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
 
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
@@ -374,6 +455,7 @@ def main():
         kmed, kmean = time_search(eng, min(args.steps, 10), 0)   # separate pass: the event reads would serialise the timed loop
         res = eng.results()
         assert (res["counts"].sum(1) == N_SIMS).all()
+        walk_c = tree_walk_bytes_continuous(eng.dump_tree(), N_SIMS, PENDULUM["c_pw"], PENDULUM["kappa"])
         # the boundary with host buffers (azg_search uploads the roots, azg_results downloads the root statistics over PCIe)
         roots = eng.synthetic_roots()
         pc = []
@@ -381,6 +463,21 @@ def main():
             t1 = time.perf_counter(); eng.search(roots); eng.results(); pc.append(time.perf_counter() - t1)
         extra["pcie_inclusive"] = {"sims_per_s": B * N_SIMS / float(np.median(pc)), "ms_per_search": float(np.median(pc)) * 1e3,
                                    "note": "azg_search (host roots in) + azg_results (host root statistics out), median of 5; never `value`"}
+        # the N > 1 workload (config D's self-play step) on this one GPU, no collectives: what the driver's 1 -> N ratio should be
+        # read against (N = 1 times config C = search + return_results; N > 1 times config D = that + final action, env step, replay row)
+        eng.selfplay_begin(200, capacity_steps=8, fifo=True)
+        for _ in range(args.warmup):
+            eng.selfplay_step()
+        eng.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.selfplay_step()
+        eng.sync()
+        dsp = time.perf_counter() - t1
+        extra["config_d_1rank"] = {"sims_per_s": B * N_SIMS * args.steps / dsp, "ms_per_step": dsp / args.steps * 1e3, "steps": args.steps,
+                                   "note": "config D's step on one GPU (search + final action + env step + replay row on the device, no collectives): "
+                                           "the like-for-like N = 1 leg of the N > 1 lines, whose `value` times this step plus the replay all-gather "
+                                           "and the weight broadcast"}
         workload = f"config C: Pendulum-v1 A0C, {B} trees/GPU x {N_SIMS} sims, 2x256 ELU policy/value MLP, c_uct=0.05 c_pw=1 kappa=0.5"
         parallelism = "1 GPU"
     else:
@@ -480,24 +577,28 @@ def main():
         elif not args.no_extra:
             extra["configs"] = [
                 extra_config("C at 8192 trees per GPU (the batch shape of real self-play runs: two 16-tree groups per CU)", PENDULUM, 8192, 200, 3, HIDDEN, 2, "elu",
-                             "search_kernel<2, 256, 1, 1, false, 8, 2>", FLOP_PER_SIM,
+                             "search_kernel<2, 256, 1, 1, false, 8, 2, 16>", FLOP_PER_SIM,
                              "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
-                             "search_kernel<0, 128, 1, 1, false, 4, 1>", 0.26 * mlp_flops(4, [128, 128], 3),
-                             "tree-walk bound (8-9 levels per trace, 0.26 evaluations per simulation): the MFMA fraction is small by construction, "
-                             "the HBM-side figure of SURVEY 8d is in roofline_hbm; selections are taken at backup time and stored with the nodes, "
-                             "the descent follows them", dev, hbm_tag="B"),
+                             B_KERNEL, None,
+                             "tree-walk bound (8-9 levels per trace, about 0.2 evaluations per simulation -- counted from the trees --: the MFMA "
+                             "fraction is small by construction, the HBM-side figure of SURVEY 8d is in roofline_hbm; selections are taken at "
+                             "backup time and stored with the nodes, the descent follows them", dev, hbm=True, live=("B", "search_kernel")),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
                              "ls_team_kernel<2, 1024, false, 1, 4, 2>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
                              "layer for the team's 32 trees each), hand-offs through global memory; traffic = L2 misses of the cross-XCD "
-                             "activation hand-offs (DESIGN.md section 3), the weights stay L2-resident", dev, traffic_tag="E"),
+                             "activation hand-offs (DESIGN.md section 3), the weights stay L2-resident", dev, live=("E", "ls_team_kernel")),
                 extra_config("E's network at 2048 trees per GPU", PENDULUM, 2048, 200, 3, [1024] * 4, 2, "elu",
                              "ls_team_kernel<2, 1024, false, 1, 2, 4>",
                              mlp_flops(3, [1024] * 4, 3), "the team kernel's four-workgroups-per-CU form (short staging chunks): while one workgroup of a CU waits "
                              "at a hand-off or walks its trees the other three keep the matrix pipe busy", dev),
             ]
-        traffic, traffic_note = None, "not measured (N > 1 loop)"
+        traffic, traffic_note = None, ("not measured in the N > 1 loop (the search kernel is the one of the N = 1 line: same launch, same "
+                                       "traffic; rocprofv3 child passes are not started from inside a running multi-rank job)")
+        if config_d and B == N_TREES:
+            traffic, src = profiled_traffic()
+            traffic_note += f"; value from the committed N = 1 passes ({src})"
         if not config_d:
             if not args.no_live_traffic:
                 traffic, why = live_traffic(B)
@@ -524,8 +625,11 @@ def main():
                                  "rate is extra.pcie_inclusive"},
             "extra": extra,
         }
-        if not config_d and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if not config_d:
+            out["roofline_hbm"] = hbm_block(*walk_c, B, N_SIMS, kmean, traffic, traffic_note)
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region (the other ranks wait at the final barrier, inside --dist-timeout)
+            out["cpu_baseline"] = cpu_baseline(short=config_d)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -88,6 +88,8 @@ struct azg_engine {
     int32_t* carry;
     uint32_t search_idx;
     int searched;
+    /* azo_trace_enable: per tree and trace, the record the trace ended in and its tightest arg-max (T3 mismatch attribution) */
+    int32_t* trace_leaf; double* trace_margin;
     /* self-play */
     int sp_on, sp_max_len, sp_det, sp_cap, sp_steps, sp_row;
     int sp_insert, sp_fs, sp_ring;
@@ -360,6 +362,7 @@ void azo_engine_destroy(azg_engine* e) {
     free(e->mlp.Wh); free(e->mlp.bh); free(e->pw_need); free(e->roots); free(e->carry);
     free(e->sp_t); free(e->sp_episode); free(e->sp_fcnt); free(e->sp_ret); free(e->sp_fsum); free(e->sp_rows);
     free(e->res_actions); free(e->res_counts); free(e->res_Q); free(e->res_vt); free(e->res_nch);
+    free(e->trace_leaf); free(e->trace_margin);
     free(e);
 }
 
@@ -397,6 +400,10 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
         e->Kmax = cfg->num_actions;
         e->R = 1 + cfg->num_actions * (ns + 1);
         e->n_dist = cfg->num_actions;
+    }
+    if (cfg->tie_break == AZG_TIE_RANDOM && e->Kmax > 16) {   /* the same limit and error as the device engine */
+        free(e->pw_need); free(e);
+        return fail(NULL, AZG_E_UNSUPPORTED, "tie_break random supports at most 16 children per node");
     }
     /* per-tree arrays are allocated by the thread that first searches the tree (first touch: pages land on its NUMA node) */
     e->trees = (tree_t*)calloc(cfg->n_trees, sizeof(tree_t));
@@ -492,6 +499,7 @@ typedef struct {
     uint32_t gtree;   /* global tree id */
     uint32_t search;
     uint32_t eps_draws;
+    double margin;    /* smallest best-minus-runner-up score gap among the arg-max selections of the current trace */
 } ctx_t;
 
 /* fill the node half of record j (MCTS.expansion, mcts.py:216-238) and evaluate it */
@@ -571,7 +579,7 @@ static int select_child(ctx_t* c, int p) {
     }
     double sq = sqrt((double)(t->node_n[p] + 1));
     int best = -1;
-    double bestU = 0.0;
+    double bestU = 0.0, secondU = 0.0;
     double Us[64];
     float cf = (float)e->cfg.c_uct;
     for (int i = 0; i < K; ++i) {
@@ -585,10 +593,13 @@ static int select_child(ctx_t* c, int p) {
         } else {
             U = t->edge_Q[k] + e->cfg.c_uct * ratio;
         }
-        if (best < 0 || U > bestU) { best = k; bestU = U; }
+        if (best < 0) { best = k; bestU = U; secondU = -INFINITY; }
+        else if (U > bestU) { secondU = bestU; best = k; bestU = U; }
+        else if (U > secondU) secondU = U;
         Us[i < 64 ? i : 63] = U;
     }
-    if (e->cfg.tie_break == AZG_TIE_RANDOM && K <= 64) {
+    if (K >= 2 && bestU - secondU < c->margin) c->margin = bestU - secondU;
+    if (e->cfg.tie_break == AZG_TIE_RANDOM) {   /* (K <= Kmax <= 16: azo_engine_create) */
         /* helpers.argmax (helpers.py:46-52): uniform among the children that hold the maximum; the draw is keyed by the node and
          * its visit count, so it does not matter when between two visits of the node the selection is taken */
         int cnt = 0;
@@ -640,6 +651,7 @@ static void search_tree(ctx_t* c, const double* root, int carry) {
     if (e->cfg.mode == AZG_MODE_CONTINUOUS) widen(c, 0);   /* mcts.py:673 */
     for (int sim = 0; sim < e->cfg.n_sims; ++sim) {
         int node = 0;
+        c->margin = INFINITY;
         while (!(t->flags[node] & FLAG_TERMINAL)) {
             int k = select_child(c, node);
             if (t->flags[k] & FLAG_EXPANDED) { node = k; continue; }
@@ -655,6 +667,10 @@ static void search_tree(ctx_t* c, const double* root, int carry) {
             break;
         }
         backup(c, node);
+        if (e->trace_leaf) {
+            size_t ti = (size_t)(t - e->trees) * e->cfg.n_sims + sim;
+            e->trace_leaf[ti] = node | ((t->parent[node] < 0 ? 0 : t->parent[node]) << 16); e->trace_margin[ti] = c->margin;
+        }
     }
 }
 
@@ -692,6 +708,24 @@ int azo_search(azg_engine* e, const double* roots, const int32_t* carry) {
     int rc = azo_upload_roots(e, roots, carry);
     if (rc) return rc;
     return azo_search_resident(e);
+}
+
+/* Checker-only diagnostics (no azg_ counterpart): from the next search on, keep for every tree and trace the record the trace
+ * ended in (low 16 bits; with its parent node's record in the high 16 bits the pair pins the trace's whole path) and the smallest gap between the best and the second-best selectionUCT score met on the way down.  The end-to-end
+ * tier (T3: reference with its torch MLP vs this arithmetic) uses them to show that a tree whose visit counts differ from the
+ * reference's left the reference's sequence of traces at an arg-max that a ~1e-7 network difference can flip. */
+int azo_trace_enable(azg_engine* e) {
+    if (!e) return AZG_E_INVALID;
+    size_t n = (size_t)e->cfg.n_trees * (size_t)e->cfg.n_sims;
+    if (!e->trace_leaf) { e->trace_leaf = (int32_t*)calloc(n, 4); e->trace_margin = (double*)calloc(n, 8); }
+    return (e->trace_leaf && e->trace_margin) ? AZG_OK : fail(e, AZG_E_STATE, "out of memory for the trace buffers");
+}
+int azo_trace_get(azg_engine* e, int32_t* leaf, double* margin) {
+    if (!e || !e->trace_leaf || !e->searched) return AZG_E_STATE;
+    size_t n = (size_t)e->cfg.n_trees * (size_t)e->cfg.n_sims;
+    if (leaf) memcpy(leaf, e->trace_leaf, n * 4);
+    if (margin) memcpy(margin, e->trace_margin, n * 8);
+    return AZG_OK;
 }
 
 int azo_sync(azg_engine* e) { (void)e; return AZG_OK; }

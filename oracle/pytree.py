@@ -140,9 +140,10 @@ def root_results(root):
 
 
 def _worker(args):
-    """One process of the throughput measurement: `n_trees` searches, returns (simulations, seconds)."""
+    """One process of the throughput measurement: whole searches until at least `n_trees` are done AND `seconds` have passed
+    (start-up -- imports, building the policy -- is outside the clock); returns (simulations, seconds)."""
     import time
-    kind, n_trees, n_rollouts, hidden, seed = args
+    kind, n_trees, n_rollouts, hidden, seed, seconds = args
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -160,23 +161,28 @@ def _worker(args):
         policy = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
                              num_actions=2)
     t0 = time.perf_counter()
-    for _ in range(n_trees):
+    done = 0
+    while done < n_trees or time.perf_counter() - t0 < seconds:
+        done += 1
         if kind == "pendulum":
             env = PendulumEnv(state=[rng.uniform(-np.pi, np.pi), rng.uniform(-1, 1)], version=1)
             search_continuous(policy, env, n_rollouts, 0.05, 1, 0.5, 1)
         else:
             env = CartPoleEnv(state=rng.uniform(-0.05, 0.05, 4))
             search_discrete(policy, env, n_rollouts, 1.5, 1)
-    return n_trees * n_rollouts, time.perf_counter() - t0
+    return done * n_rollouts, time.perf_counter() - t0
 
 
-def throughput(kind="pendulum", n_rollouts=200, hidden=(256, 256), processes=1, trees_per_process=2):
-    """sims/s of `processes` worker processes x 1 torch thread = total simulations / slowest worker's wall time."""
+def throughput(kind="pendulum", n_rollouts=200, hidden=(256, 256), processes=1, trees_per_process=2, seconds=0.0, detail=False):
+    """sims/s of `processes` worker processes x 1 torch thread.  Every worker searches at least `trees_per_process` trees and
+    for at least `seconds` of its own clock (the workers run side by side for that time); the rate is total simulations /
+    slowest worker's wall time.  detail: also return (total simulations, slowest worker's seconds)."""
     import multiprocessing as mp
-    args = [(kind, trees_per_process, n_rollouts, list(hidden), 100 + i) for i in range(processes)]
+    args = [(kind, trees_per_process, n_rollouts, list(hidden), 100 + i, float(seconds)) for i in range(processes)]
     if processes == 1:
         res = [_worker(args[0])]
     else:
         with mp.get_context("spawn").Pool(processes) as pool:
             res = pool.map(_worker, args)
-    return sum(r[0] for r in res) / max(r[1] for r in res)
+    rate = sum(r[0] for r in res) / max(r[1] for r in res)
+    return (rate, sum(r[0] for r in res), max(r[1] for r in res)) if detail else rate

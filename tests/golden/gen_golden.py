@@ -4,6 +4,7 @@
     python tests/golden/gen_golden.py            # needs /root/reference; writes tests/golden/*.npz
     python tests/golden/gen_golden.py t7         # only the self-play tier
     python tests/golden/gen_golden.py t1 NAME... # only the named T1 cases
+    python tests/golden/gen_golden.py scale      # only t3_scale.npz (T3 on 1024 config-C, 1024 config-B, 64 config-E roots; ~5 min on 8 cores)
     python tests/golden/gen_golden.py wide       # only t2_mlp_wide.npz (4x1024, 2x512), t3_full_rollouts.npz (n_rollouts = 200), t5_update.npz
 
 The reference (timoklein/alphazero-gym) is imported unmodified from /root/reference.  `gym`, `hydra`
@@ -576,6 +577,144 @@ def run_t3_full():
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------- T3 at scale
+def _leaf_log():
+    """Record, per trace, the engine record id of the node MCTS.backprop starts from (mcts.py:241-267)."""
+    log = []
+    orig = RM.MCTS.backprop
+
+    def traced(node, gamma):
+        rec = node.parent_action._rec if node.parent_action is not None else 0
+        up = node.parent_action.parent_node.parent_action if node.parent_action is not None else None
+        log.append(rec | ((up._rec if up is not None else 0) << 16))   # (leaf record, its parent node's record): pins the trace's path
+        return orig(node, gamma)
+
+    return log, orig, staticmethod(traced)
+
+
+def _t3_scale_chunk(job):
+    """One worker's share of a T3-at-scale leg: global tree ids [lo, hi) of `kind` ('c' / 'e': Pendulum-v1 continuous with the
+    reference's DiagonalNormalPolicy; 'b': CartPole discrete with its DiscretePolicy)."""
+    kind, hidden, n_rollouts, lo, hi, roots, seed = job
+    torch.set_num_threads(1)
+    cont = kind != "b"
+    if cont:
+        blob = O.make_weights(34, 3, hidden, 2)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                          num_components=1, action_bound=2.0)
+        set_policy_weights(pol, blob, 3, hidden, 2)
+    else:
+        blob = O.make_weights(34, 4, hidden, 2)
+        pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
+                          num_actions=2)
+        set_policy_weights(pol, blob, 4, hidden, 2)
+    res = []
+    orig_normal = torch.normal
+    log, orig_bp, traced = _leaf_log()
+    RM.MCTS.backprop = traced
+    TIES["n"] = 0
+    try:
+        for ti in range(lo, hi):
+            state = {"n": 0}
+
+            def fake_normal(mean, std, *a, **k):
+                state["n"] += 1
+                eps = O.normal(seed, ti, 0, state["n"])
+                return mean + std * np.float32(eps)
+
+            torch.normal = fake_normal
+            COUNTER["n"] = 0
+            del log[:]
+            if cont:
+                env = PendulumEnv(state=roots[ti - lo], version=1)
+                m = RM.MCTSContinuous(model=pol, n_rollouts=n_rollouts, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                                      V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
+            else:
+                env = CartPoleEnv(state=roots[ti - lo])
+                m = RM.MCTSDiscrete(model=pol, num_actions=2, n_rollouts=n_rollouts, c_uct=1.5, gamma=1, epsilon=0.0,
+                                    V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
+            m.search(env)
+            s, actions, counts, Q, V = m.return_results("max_visit")
+            res.append((np.asarray(counts, np.int32).reshape(-1), np.array([np.asarray(q).reshape(-1)[0] for q in Q], np.float64),
+                        np.asarray(actions, np.float32).reshape(-1), float(np.asarray(V).reshape(-1)[0]), np.array(log, np.int32)))
+    finally:
+        torch.normal = orig_normal
+        RM.MCTS.backprop = orig_bp
+    return lo, res, TIES["n"]
+
+
+T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engine kwargs)   -- BASELINE configs C, B, E
+    "c": (2, 1, [256, 256], "elu", 200, 4096, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
+    "b": (0, 0, [128, 128], "relu", 100, 4096, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
+    "e": (2, 1, [1024] * 4, "elu", 200, 128, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
+}
+T3_SCALE_FULL = 1024   # trees per leg whose Q / actions / value target are stored as well (visit counts: every tree)
+
+
+def run_t3_scale(procs=8):
+    """T3 at BASELINE scale (VERDICT r03 row g): the reference's MCTSContinuous.search / MCTSDiscrete.search (mcts.py:418-462,
+    656-702) with its REAL torch policies (policies.py:340-352, 436-499) on the engine's own synthetic roots 0..N-1 of configs C
+    (all 4096 trees, 2x256 ELU, 200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU,
+    200 rollouts).  Stored: visit counts of every tree (uint8); Q, actions and value target of the first 1024 trees of a leg.  The generator also runs the C oracle on the same roots;
+    for every tree whose counts differ it stores the reference's per-trace leaf records, so that the test can locate the first
+    diverging trace and show that the oracle's arg-max there was a near-tie."""
+    import multiprocessing as mp
+    out = {}
+    for tag, (env_id, mode, hidden, act, n_roll, B, kw) in T3_SCALE.items():
+        eng = O.OracleEngine(env_id=env_id, mode=mode, n_trees=B, n_sims=n_roll, seed=34, **kw)
+        roots = eng.synthetic_roots()
+        n_dist = 2
+        eng.set_weights(_capi.make_desc(4 if mode == 0 else 3, hidden, n_dist, act), O.make_weights(34, 4 if mode == 0 else 3, hidden, n_dist))
+        eng.trace_enable()
+        eng.search(roots)
+        ro = eng.results()
+        o_leaf, o_margin = eng.trace_get()
+        eng.close()
+        per = max(1, B // (procs * 4))
+        jobs = [(tag, hidden, n_roll, lo, min(B, lo + per), roots[lo:min(B, lo + per)], 34) for lo in range(0, B, per)]
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_t3_scale_chunk, jobs)
+        parts.sort(key=lambda x: x[0])
+        ties = sum(p[2] for p in parts)
+        assert ties == 0, f"t3 scale {tag}: {ties} exact arg-max ties in the reference run"
+        rows = [r for p in parts for r in p[1]]
+        K = ro["counts"].shape[1]
+        F = min(B, T3_SCALE_FULL)
+        counts = np.zeros((B, K), np.uint8); Q = np.zeros((F, K), np.float64); actions = np.zeros((F, K), np.float32)
+        nch = np.zeros(B, np.uint8); vt = np.zeros(F, np.float64)
+        mism, mism_leaf = [], []
+        for i, (c, q, a, v, leaf) in enumerate(rows):
+            k = len(c)
+            assert c.max() < 256
+            nch[i] = k; counts[i, :k] = c
+            if i < F:
+                Q[i, :k] = q; actions[i, :k] = a; vt[i] = v
+            same = k == ro["n_children"][i] and (ro["counts"][i][:k] == c).all()
+            if not same:
+                mism.append(i); mism_leaf.append(leaf)
+        out[f"{tag}_roots"] = roots; out[f"{tag}_counts"] = counts; out[f"{tag}_Q"] = Q; out[f"{tag}_n_children"] = nch
+        out[f"{tag}_v_target"] = vt
+        if mode == 1:
+            out[f"{tag}_actions"] = actions
+        out[f"{tag}_mismatch_ids"] = np.array(mism, np.int32)
+        out[f"{tag}_mismatch_ref_leaf"] = np.stack(mism_leaf).astype(np.int32) if mism else np.zeros((0, n_roll), np.int32)
+        finite = o_margin[np.isfinite(o_margin)]
+        print(f"t3 scale {tag}: {B} trees, {len(mism)} with different visit counts (match rate {1 - len(mism) / B:.4f}); "
+              f"oracle arg-max gaps: min {finite.min():.3e}, {int((finite < 1e-6).sum())} of {finite.size} below 1e-6", flush=True)
+        for i, leaf in zip(mism, mism_leaf):
+            d = int(np.argmax(leaf != o_leaf[i]))
+            print(f"   tree {i}: first diverging trace {d}, oracle's tightest arg-max gap on it {o_margin[i, d]:.3e}")
+    return out
+
+
+def main_scale():
+    res = run_t3_scale()
+    path = os.path.join(HERE, "t3_scale.npz")
+    np.savez_compressed(path, **res)
+    print("t3_scale.npz", os.path.getsize(path), "bytes")
+
+
 def main_wide():
     t5u = run_t5_update()
     np.savez_compressed(os.path.join(HERE, "t5_update.npz"), **t5u)
@@ -962,6 +1101,8 @@ def main():
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
             print(name, "records", res["n_records"].tolist(), "counts", res["counts"].tolist())
         return
+    if sys.argv[1:] == ["scale"]:  # only t3_scale.npz: the reference with its torch policies on 4096 + 4096 + 128 synthetic roots
+        return main_scale()
     if sys.argv[1:] == ["wide"]:   # only the wide-network T2 cases and the n_rollouts = 200 T3 legs
         return main_wide()
     for name, case in T1_CASES.items():
@@ -989,6 +1130,7 @@ def main():
     print("t3 ties", TIES["n"], "c_counts[0]", t3["c_counts"][0].tolist(), "d_counts", t3["d_counts"].tolist())
     main_t7()
     main_wide()
+    main_scale()
 
 if __name__ == "__main__":
     main()

@@ -67,6 +67,22 @@ class OracleEngine(_capi.Engine):
     def __init__(self, **kw):
         super().__init__(fns(), **kw)
 
+    def trace_enable(self):
+        """Keep, from the next search on, every trace's final record and tightest arg-max gap (azo_trace_enable)."""
+        f = lib().azo_trace_enable
+        f.argtypes = [C.c_void_p]
+        self._check(f(self._h))
+
+    def trace_get(self):
+        """(leaf [B, n_sims] int32: the trace's final record | its parent node's record << 16, margin [B, n_sims] float64: the
+        trace's tightest arg-max gap) of the last search."""
+        f = lib().azo_trace_get
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        leaf = np.empty((self.n_trees, self.n_sims), np.int32)
+        margin = np.empty((self.n_trees, self.n_sims), np.float64)
+        self._check(f(self._h, _capi._ptr(leaf, C.c_int32), _capi._ptr(margin, C.c_double)))
+        return leaf, margin
+
 
 def normal(seed, tree, search, draw):
     return float(lib().azo_normal(seed, tree, search, draw))

@@ -37,9 +37,9 @@ def main():
     lib.azg_debug_kernel_name(C.c_void_p(e._h.value), name, C.c_size_t(256))
     print("kernel", name.value.decode())
     args = name.value.decode().split("<")[1].rstrip(">").split(",")
-    waves, groups = int(args[5]), int(args[6])             # search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG>
-    rows = (B + 16 * groups - 1) // (16 * groups) * waves   # one row per wave
-    buf = np.zeros((max(rows, (B + 15) // 16 * 8), 16), np.uint64)
+    waves, groups, nt = int(args[5]), int(args[6]), int(args[7])   # search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG, NT>
+    rows = (B + nt * groups - 1) // (nt * groups) * waves   # one row per wave
+    buf = np.zeros((max(rows, (B + 3) // 4 * 4), 16), np.uint64)
     lib.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
     n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf))
     assert n >= rows
