@@ -180,7 +180,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.force_global_tree = env_digit("AZG_FORCE_GLOBAL_TREE", 0) == 1;
     e->opt.waves = env_digit("AZG_WAVES", 0);
     e->opt.groups = env_digit("AZG_GROUPS", 0);
-    { const char* v = getenv("AZG_TILE_TREES"); const int t = v ? atoi(v) : 0; e->opt.tile_trees = (t == 16 || t == 8 || t == 4) ? t : 0; }
+    { const char* v = getenv("AZG_TRACE_CAP"); const int t = v ? atoi(v) : 0; e->opt.trace_cap = t > 0 ? t : 0; }
+    { const char* v = getenv("AZG_TILE_TREES"); const int t = v ? atoi(v) : 0; e->opt.tile_trees = (t == 16 || t == 8) ? t : 0; }
     e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
     e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
@@ -281,6 +282,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     HK(hipMemset(hot, 0, B * R * sizeof(RecL)));
     HK(hipMemset(e->d_carry, 0, B * sizeof(int)));
     P.B = cfg->n_trees; P.n_sims = ns; P.R = e->R; P.Kp = e->Kp; P.A = cfg->num_actions; P.nd = e->nd;
+    P.trace_cap = e->opt.trace_cap > 0 ? e->opt.trace_cap : 4;
     P.tie_random = cfg->tie_break == AZG_TIE_RANDOM; P.env_id = cfg->env_id; P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
     P.c_uct = cfg->c_uct; P.gamma = cfg->gamma; P.epsilon = cfg->epsilon; P.reward_scale = cfg->reward_scale;
     P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;

@@ -89,18 +89,16 @@ static hipError_t launch(azg_engine* e) {
             if (rc != hipErrorInvalidConfiguration) return rc;
         }
     }
-    // Half-filled tiles (small register-resident networks, LDS trees): a batch that cannot give every CU two 16-tree workgroups is
-    // cut into 8-tree workgroups -- two per CU at 4096 trees on 256 CUs -- or, when even those are fewer than two per CU, 4-tree
-    // ones.  AZG_TILE_TREES=16|8|4 forces a shape (tests).
+    // Half-filled tiles (small register-resident networks, LDS trees): batches of at most 8 trees per CU run as 8-tree workgroups
+    // (search_kernel.cuh has the measurements: with more trees than that, full tiles win).  AZG_TILE_TREES=16|8 forces a shape (tests).
     if constexpr (HP <= 128 && NREG == 1) {
         if (ts == TS_LDS8 && e->P.ncomp < 2) {
-            const long g16 = (e->cfg.n_trees + 15) / 16, g8 = (e->cfg.n_trees + 7) / 8;
-            int nt = g16 >= 2L * e->n_cus ? 16 : (g8 >= 2L * e->n_cus ? 8 : 4);
+            int nt = e->cfg.n_trees <= 8L * e->n_cus ? 8 : 16;
             if (e->opt.tile_trees) nt = e->opt.tile_trees;
-            hipError_t rc = hipErrorInvalidConfiguration;
-            if (nt == 4) rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1, 4>(e);
-            if (nt == 8 || (nt == 4 && rc == hipErrorInvalidConfiguration)) rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1, 8>(e);
-            if (rc != hipErrorInvalidConfiguration) return rc;
+            if (nt == 8) {
+                hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1, 8>(e);
+                if (rc != hipErrorInvalidConfiguration) return rc;
+            }
         }
     }
     if (ts == TS_LDS8) {

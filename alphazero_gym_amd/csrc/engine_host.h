@@ -16,7 +16,8 @@ struct EngineOptions {
     int force_global_tree;     // AZG_FORCE_GLOBAL_TREE=1: trees in global memory instead of LDS
     int waves;                 // AZG_WAVES=4|8 (0: automatic)
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
-    int tile_trees;            // AZG_TILE_TREES=16|8|4: trees per 16-column MFMA tile of the small-network kernels (0: automatic)
+    int trace_cap;             // AZG_TRACE_CAP=n: traces a discrete tree may run per simulation step (0: automatic)
+    int tile_trees;            // AZG_TILE_TREES=16|8: trees per 16-column MFMA tile of the small-network kernels (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
     // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
     int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of

@@ -64,6 +64,10 @@ __device__ __forceinline__ void discrete_env_step(int env_id, const double* s, i
     else cartpole_step(s, action, o, reward, done);
 }
 
+// Every step of the discrete family's environments pays the same reward (CartPole +1, MountainCar -1): the tree walk takes a
+// path record's reward from here instead of loading it (the node records still hold it, for dumps and the generic backup).
+__device__ __forceinline__ double discrete_env_reward(int env_id) { return env_id == AZG_ENV_MOUNTAINCAR ? -1.0 : 1.0; }
+
 // gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node
 __device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {
     const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;

@@ -111,6 +111,7 @@ struct KParams {
     int res_Kmax, res_v_target;
     int tie_random;             // AZG_TIE_RANDOM: exactly equal selection scores are broken by a Philox draw instead of by lowest index
     int env_id;                 // AZG_ENV_* (the discrete family's kernels serve CartPole and MountainCar: env step chosen at run time)
+    int trace_cap;              // discrete mode: traces a tree may run per simulation step (search_kernel.cuh; >= 1)
     int lds_state;              // discrete LDS trees: the env states of expanded nodes live in LDS too (set by the launch planning)
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };

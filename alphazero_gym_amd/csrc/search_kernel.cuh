@@ -4,9 +4,12 @@
 //   NW = 8, NG = 1: two waves per SIMD, 2 trees per wave: half the activation math and less tree-walk divergence per wave;
 //   NW = 8, NG = 2: two waves per SIMD, 32 trees: one wave's tree walk / activation math overlaps the other's MFMAs
 //                   (pays off when the batch has more 16-tree groups than the device has CUs).
-// NT < 16 ("half-filled tiles"): a group holds only NT = 8 or 4 trees, the other columns of its MFMA tile carry zeros.  A batch that
-// would leave every CU with ONE 16-tree workgroup (4096 trees on 256 CUs) becomes two or four workgroups per CU, whose serial
-// tree-walk chains then overlap; the matrix pipe is nearly idle in those shapes (small networks), so the empty columns are free.
+// NT < 16 ("half-filled tiles"): a group holds only NT = 8 (or 4) trees, the other columns of its MFMA tile carry zeros: more,
+// smaller workgroups.  Measured on MI355X (config B's network, ms per search at 2048 / 4096 / 8192 trees): NT = 16: 0.469 / 0.482 /
+// 0.626; NT = 8: 0.451 / 0.594 / 1.115; NT = 4: 0.549 / 1.049 / 2.040.  A step of a workgroup takes about as long with 8 trees
+// as with 16 (it is a chain of dependent instructions, not a throughput problem), and two workgroups that share a CU slow each
+// other down by about 30 %: splitting 4096 trees into 512 half-filled workgroups (two per CU) LOSES 23 % against 256 full ones.
+// NT = 8 is used where it does pay: batches of at most 8 trees per CU (one workgroup per CU either way, fewer trees per wave: -4 %).
 #pragma once
 #include "records.h"
 #include "env.cuh"
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     __shared__ float s_obsT[4 * TPW];
     __shared__ float s_bhead[16];
     __shared__ float s_ln[NREG == 0 ? 2 * 64 : 1];
+    __shared__ int s_done;              // discrete mode: trees of this workgroup that have finished their last trace
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] u16, activation buffers, (TLDS) the trees' hot records
 
     const int tid = threadIdx.x;
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     for (int i = tid; i < P.tab_n; i += 64 * NW) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 64 * NW) s_pw[i] = (unsigned short)(P.pw_need[i] < 65535 ? P.pw_need[i] : 65535);
     if (tid < 16) s_bhead[tid] = P.bhead[tid];
+    if (tid == 0) s_done = 0;
 
     // register-resident weights
     WRegs<HP, NREG, NW> wr;
@@ -138,12 +143,24 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     if (cx.has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tree, cx.live, cx.sub, cx.tl, cx.gtree, s_obsT);
     __syncthreads();
 
-    for (int sim = -1; sim < P.n_sims; ++sim) {
+    // Discrete mode: a tree's traces need a network evaluation only when they create a non-terminal node (CartPole at config B: one
+    // trace in five; the others end in a terminal node).  A tree therefore runs up to P.trace_cap traces per step: after backing up
+    // a trace that needed no evaluation it starts its next one right away, until a trace does need the network (or the cap is
+    // reached: the trees of a wave walk in SIMT lock step, so a tree that keeps going holds up the ones that are waiting for
+    // their evaluation).  The order of a tree's traces and everything they compute is unchanged; what changes is how many network
+    // phases and barriers a search takes (config B: 101 -> about 40).  Every tree counts its own traces (my_sim); the workgroup
+    // leaves when all of its trees are done (s_done, read by everyone right after the step's first barrier).
+    // Continuous mode (every trace widens a node and evaluates the new leaf): one trace per step, as before.
+    constexpr bool MULTI = !CONT;
+    int my_sim = -1;                    // the trace whose leaf is pending (-1: the root's evaluation); n_sims: the tree is done
+    const int n_live = (P.B - (int)blockIdx.x * TPW) < TPW ? (P.B - (int)blockIdx.x * TPW) : TPW;
+    for (int sim = -1; MULTI || sim < P.n_sims; ++sim) {
         // ================= network phase: evaluate the pending leaves =================
         STAMP(t_a);
         // one barrier: the observations of phase B are visible.  The network runs even if every pending leaf of the workgroup is
         // terminal (rare; its outputs are then ignored): testing for that costs two more barriers per step (__syncthreads_or)
         __syncthreads();
+        if constexpr (MULTI) { if (*(volatile int*)&s_done >= n_live) break; }   // (uniform: nobody adds to s_done before the network phase's barriers)
         STAMP(t_b);
         unsigned pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;
         int tid_o = tid;
@@ -171,22 +188,57 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             cx = make_ctx(tid_o);
             // the path's rewards and cumulative returns (the descent did not fetch them: tree_phase_b<..., FETCH = false>)
             st.pr = 0.0; st.pW = 0.0;
-            if (cx.live && sim >= 0 && st.my_depth >= 1) { st.pr = cx.cold[st.pid].r; st.pW = cx.edge_W[st.pid]; }
+            if (cx.live && (MULTI ? my_sim : sim) >= 0 && st.my_depth >= 1) {
+                st.pr = CONT ? cx.cold[st.pid].r : discrete_env_reward(P.env_id);
+                st.pW = cx.edge_W[st.pid];
+            }
         }
-        // ================= tree phase A: finish the evaluated leaf, back up =================
-        if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
-        if (sim == P.n_sims - 1) break;
-        __threadfence_block();
-        STAMP(t_d);
-        // ================= tree phase B: next trace: select down, step the env, expand =================
-        st.need_eval = false;
-        if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
-        __threadfence_block();
-        STAMP(t_e);
+        if constexpr (!MULTI) {
+            // ================= tree phase A: finish the evaluated leaf, back up =================
+            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+            if (sim == P.n_sims - 1) break;
+            __threadfence_block();
+            STAMP(t_d);
+            // ================= tree phase B: next trace: select down, step the env, expand =================
+            st.need_eval = false;
+            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+            __threadfence_block();
+            STAMP(t_e);
+            STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
+            STAMP_ADD(3, t_d, t_e);   // select / step / expand
+        } else {
+            // ================= tree phases A and B, up to trace_cap times: back up, start the next trace, until one needs the network
+            bool run = cx.live && my_sim < P.n_sims;
+            int k = 0;
+            while (run) {
+                STAMP(t_c2);
+                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+                __threadfence_block();
+                STAMP(t_d);
+                st.need_eval = false;
+                if (my_sim == P.n_sims - 1) {
+                    my_sim = P.n_sims;                          // the tree's last trace is backed up
+                    if (cx.sub == 0) atomicAdd(&s_done, 1);
+                    run = false;
+                } else {
+                    my_sim += 1;
+                    tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+                    __threadfence_block();
+                    k += 1;
+                    if (st.need_eval || k >= P.trace_cap) run = false;
+                    else if constexpr (LEAN) {
+                        // (the lean descent leaves the path's rewards / returns to be fetched before the backup)
+                        st.pr = 0.0; st.pW = 0.0;
+                        if (st.my_depth >= 1) { st.pr = discrete_env_reward(P.env_id); st.pW = cx.edge_W[st.pid]; }
+                    }
+                }
+                STAMP(t_e);
+                STAMP_ADD(2, t_c2, t_d);   // finish leaf + backup
+                STAMP_ADD(3, t_d, t_e);    // select / step / expand
+            }
+        }
         STAMP_ADD(0, t_a, t_b);   // wait at the barrier in front of the network phase
         STAMP_ADD(1, t_b, t_c);   // network phase
-        STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
-        STAMP_ADD(3, t_d, t_e);   // select / step / expand
     }
     const int nrec = st.nrec;
     const int sub = cx.sub, tree = cx.tree;

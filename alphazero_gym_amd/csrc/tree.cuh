@@ -225,26 +225,37 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 
 // Backup of a trace whose path the descent left in the lanes: slot (depth & 15) holds the record id, its reward and W
 // (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
+// On return pW holds the slot's updated W and `rec` the slot's updated record (zeros in lanes without a slot); `chainR` is the
+// lane's return of this trace.  same_chain: the trace is the previous one again (same path, same terminal leaf, see
+// tree_phase_b): every lane's return is the one it had, the serial chain is skipped.
 template <bool CONT, int TLDS, typename F>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
-                                            double gamma, int D, int my_depth, int pid, double pr, double pW, F&& on_node) {
+                                            double gamma, int D, int my_depth, int pid, double pr, double& pW, F&& on_node,
+                                            typename TreeStore<TLDS>::Rec& rec, double& chainR, bool same_chain = false) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
     // the return travels down the path one lane per step on the DPP network: slot (depth & 15) reads its deeper neighbour's
     // value (lane sub + 1, the slot of depth + 1) and adds its own reward -- the same serial chain, no LDS shuffles
+    if (same_chain) {
+        myR = chainR;
+    } else {
 #pragma unroll 1
-    for (int d = 0; d < n0; ++d) {
-        const int src = (D - d) & 15;
-        const double nb = dpp_f64<DPP_ROW_ROR15>(myR);
-        const double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * nb;
-        if (sub == src) myR = pr + gR;
+        for (int d = 0; d < n0; ++d) {
+            const int src = (D - d) & 15;
+            const double nb = dpp_f64<DPP_ROW_ROR15>(myR);
+            const double gR = d == 0 ? (CONT ? (double)(gamma_f * V) : gamma * (double)V) : gamma * nb;
+            if (sub == src) myR = pr + gR;
+        }
+        chainR = myR;
     }
     if (D >= 16) Rv = __shfl(myR, (D - 15) & 15, 16);
     const bool valid = my_depth >= 0 && my_depth > D - 16;
     int par = 0;
+    rec = make_edge<Rec>(0.0, 0);
+    clear_pad(rec);
     if (valid) {
-        Rec rec = ts.hot[pid];
+        rec = ts.hot[pid];
         par = rec.parent;
         if (my_depth >= 1) {
             int en = (int)rec.edge_n + 1;
@@ -252,6 +263,7 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
             rec.Q = tree_div(Wn, (double)en);
             rec.edge_n = (decltype(rec.edge_n))en;
             edge_W[pid] = Wn;
+            pW = Wn;
         }
         if (my_depth < D) rec.node_n = (decltype(rec.node_n))(rec.node_n + 1);
         ts.hot[pid] = rec;

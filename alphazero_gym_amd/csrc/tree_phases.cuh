@@ -19,6 +19,8 @@ struct TreeState {
     float eps_c;          // per lane
     int ptop;             // LDS trees: next free 4-byte unit of the child-list pool
     int resume;           // discrete mode with cached selections: depth at which the next descent leaves the path of this trace (0: the root)
+    double chainR;        // per lane: the slot's return of the last backup (reused when the next trace is the same trace again)
+    bool repeat;          // the pending trace is the previous one again: same path, same terminal leaf (set by tree_phase_b)
 };
 
 // ---- the cached selection of a node ("best"): the child the next descent through the node will take.
@@ -139,11 +141,13 @@ __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<T
 // Discrete mode, two actions: every node of the path at once, each by the lane that holds its path slot (slot d & 15 = depth d,
 // record `pid`): the lane reads its node and the node's two children, scores both and stores the winner's index -- no
 // cross-lane traffic at all.  `mine`: the lane's slot holds a node of this path above the leaf.
+// hp: the lane's own record as backup_path left it (no second read; lanes without a slot hold a zero record, whose "children"
+// are records 0 and 1: valid addresses, results unused).
 template <int ENV, int TLDS>
-__device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt) {
+__device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt,
+                                                     const typename TreeStore<TLDS>::Rec& hp) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int p = mine ? pid : 0;
-    const Rec hp = ts.hot[p];
     double sq;
     if ((int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
@@ -168,7 +172,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
     st.path_D = 0; st.my_depth = -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
-    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0; st.resume = 0;
+    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0; st.resume = 0; st.chainR = 0.0; st.repeat = false;
     if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
         double rs[S], sn;
 #pragma unroll
@@ -301,8 +305,10 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
         const bool keep = !CONT && P.epsilon == 0.0 && !P.tie_random;   // (cached selections: discrete mode, see rec_best)
+        Rec myrec;
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
-                                [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); });
+                                [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); }, myrec, st.chainR,
+                                RESUME && !CONT && st.repeat);   // (only the kernels that resume descents set st.repeat)
         if constexpr (!CONT) {
             if (keep) {
                 // the selections of the path's nodes, with their new statistics: depths D-1 .. max(0, D-15) are in the lanes' slots
@@ -312,7 +318,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 if (P.A == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
                     const bool mine = st.my_depth >= lo && st.my_depth < D;
-                    const int win = refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, mine, s_sqrt);
+                    const int win = refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, mine, s_sqrt, myrec);
                     if constexpr (RESUME) {
                         // The next trace follows the stored selections from the root: it walks this trace's path for as long as every
                         // node's (re-taken) selection is still the path's next record, i.e. down to the shallowest node whose
@@ -350,6 +356,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     }
     int p = 0;
     bool resumed = false;
+    st.repeat = false;
     if constexpr (RESUME && !CONT) {
         if (P.epsilon == 0.0 && !P.tie_random && P.A == 2 && st.resume > 0) {
             // same path as a descent from the root down to depth `resume` (tree_phase_a): go on from that node
@@ -359,6 +366,10 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             st.path_D = st.resume;
         }
     }
+    // discrete mode: every step of the env pays the same reward, and a path slot that survives from the last trace (depths 1 ..
+    // resume) still holds its record's W as the last backup left it: only records that enter the path are fetched
+    const double r_step = CONT ? 0.0 : discrete_env_reward(P.env_id);
+    const bool keep_slot = !CONT && FETCH && resumed && st.my_depth >= 1;
     Rec hp = ts.hot[p];
     Cold cp;             // cold part of the current node, prefetched one level ahead
     bool from_cold = true;
@@ -366,10 +377,13 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     if (from_cold) cp = cold[p];   // (p: the root, or the node a resumed descent starts from)
     else { cp.s[0] = cp.s[1] = cp.s[2] = cp.s[3] = 0.0; }
     if (!resumed) { st.path_D = 0; st.my_depth = sub == 0 ? 0 : -1; st.pid = 0; }
-    st.pr = 0.0; st.pW = 0.0;
+    if (!keep_slot) { st.pr = 0.0; st.pW = 0.0; }
     int chosen = 0;
     bool widen = false, hit_terminal = false;
-    if constexpr (RESUME && !CONT) hit_terminal = resumed && (hp.flags & FLAG_TERMINAL);   // (the old trace ended in a terminal node and nothing moved)
+    if constexpr (RESUME && !CONT) {
+        hit_terminal = resumed && (hp.flags & FLAG_TERMINAL);   // (the old trace ended in a terminal node and nothing moved)
+        st.repeat = FETCH && hit_terminal;                       // the same trace again: same slots, same rewards, V = 0 both times
+    }
     STAMP(tb0);
     while (!hit_terminal) {
         STAMP(tl0);
@@ -404,6 +418,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             // continuous mode (2-3 levels, a slow scored descent): fetched here, in the shadow of the level's LDS waits;
             // discrete mode (8-9 levels of pointer chasing): all levels at once after the loop (measured both ways)
             if (CONT && FETCH) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
+            if (!CONT && FETCH) { st.pr = r_step; st.pW = edge_W[chosen]; }   // (consumed by the backup; requested as the record enters the path)
         }
         if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
             if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
@@ -422,7 +437,6 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         st_acc[12] += 1;
 #endif
     }
-    if (!CONT && FETCH && st.my_depth >= 1) { st.pr = cold[st.pid].r; st.pW = edge_W[st.pid]; }   // (consumed after the network phase: latency hidden)
     STAMP(tb1);
     STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {

@@ -140,13 +140,16 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2"])
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2",
+                                     "trace_cap1", "trace_cap64", "tile16"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
     instead of LDS, for wide networks (default: the persistent team kernel) the one-launch search kernel and the per-layer
     launches, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
-    itself only for batches of more 16-tree groups than CUs)."""
+    itself only for batches of more 16-tree groups than CUs); in discrete mode one trace per simulation step (the round-3 loop)
+    and as many as a tree can run without the network (default: at most four); full 16-tree tiles where small batches of small
+    networks take half-filled ones."""
     env, mode, hidden, act, n_sims, extra = cfg
     extra = dict(extra)
     ncomp = extra.pop("_ncomp", 0)
@@ -159,6 +162,14 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         if hidden != [256, 256] or ln or ncomp:
             pytest.skip("the 8-wave workgroups exist for 2x256 Normal / 2-action networks")
         monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
+    if variant in ("trace_cap1", "trace_cap64"):
+        if mode != 0 or max(hidden) > 256:
+            pytest.skip("several traces per step: the discrete persistent search kernels")
+        monkeypatch.setenv("AZG_TRACE_CAP", variant[len("trace_cap"):])
+    if variant == "tile16":
+        if max(hidden) > 128 or len(hidden) != 2 or ln or ncomp:
+            pytest.skip("half-filled tiles exist for register-resident networks up to 128 wide")
+        monkeypatch.setenv("AZG_TILE_TREES", "16")
     if variant in ("persistent", "launches"):
         if max(hidden) <= 256:
             pytest.skip("lock-step kernels only exist for hidden widths >= 512")
@@ -486,6 +497,11 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=int(rng.integers(1, 1 << 30)), tree_id_base=int(rng.integers(0, 1000)), **extra)
     if os.environ.get("AZG_FUZZ_SHAPES"):   # tools/fuzz_parity.py: also the 8-wave workgroup shapes, global trees, weights from L2
         os.environ.pop("AZG_WAVES", None); os.environ.pop("AZG_GROUPS", None); os.environ.pop("AZG_FORCE_GLOBAL_TREE", None); os.environ.pop("AZG_FORCE_STREAM_WEIGHTS", None)
+        os.environ.pop("AZG_TRACE_CAP", None); os.environ.pop("AZG_TILE_TREES", None)
+        cap = int(rng.choice([0, 0, 1, 2, 3, 7, 1000]))
+        if cap: os.environ["AZG_TRACE_CAP"] = str(cap)
+        tile = int(rng.choice([0, 8, 16]))
+        if tile: os.environ["AZG_TILE_TREES"] = str(tile)
         pick = int(rng.integers(0, 6))
         if pick == 1: os.environ["AZG_WAVES"] = "8"
         if pick == 2: os.environ["AZG_GROUPS"] = "2"
