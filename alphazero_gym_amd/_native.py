@@ -17,6 +17,43 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+class HipRuntimeConflict(NativeLibraryMissing):
+    """Two different libamdhip64 files would end up (or are) mapped in this process."""
+
+
+def mapped_hip_runtimes():
+    """Real paths of the libamdhip64 files mapped into this process (Linux: /proc/self/maps)."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line and "/" in line:
+                    found.add(os.path.realpath(line[line.index("/"):].strip()))
+    except OSError:
+        pass
+    return found
+
+
+def _check_load_order():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's) and load it by path.  If some other HIP
+    runtime is mapped already -- an embedding application loaded this engine, or another HIP library, before anything imported
+    torch -- importing torch now gives the process two runtimes, and torch.cuda then reports no GPU or hangs.  Say so instead."""
+    import importlib.util
+    import sys
+    have = mapped_hip_runtimes()
+    if not have or "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled) and os.path.realpath(bundled) not in have:
+        raise HipRuntimeConflict(
+            f"a HIP runtime is already mapped in this process ({', '.join(sorted(have))}) and PyTorch, which has not been imported yet, "
+            f"bundles another one ({bundled}): with both loaded torch.cuda finds no GPU or hangs. Import torch before anything loads "
+            "libazgym_hip.so or another HIP library (INTEGRATION.md section 1).")
+
+
 def lib():
     global _lib, _fns
     if _lib is None:
@@ -30,11 +67,17 @@ def lib():
         # system runtime, a later torch.cuda initialisation fails ("No HIP GPUs are available"); so torch, when present, goes first.
         # (Round 3 tried loading torch's runtime copy by path instead of importing torch: engine-first then worked in one GPU run
         # and hung in torch's CUDA initialisation in the next -- reverted.)
+        _check_load_order()
         try:
             import torch  # noqa: F401
         except ImportError:
             pass
         _lib = C.CDLL(LIB_PATH)
+        both = mapped_hip_runtimes()
+        if len(both) > 1:
+            _lib = None
+            raise HipRuntimeConflict(f"two HIP runtimes are mapped in this process ({', '.join(sorted(both))}): import torch before anything "
+                                     "else loads a HIP library (INTEGRATION.md section 1)")
         _fns = _capi.bind(_lib, "azg_")
         ver = _fns["abi_version"]()
         if ver != _capi.ABI_VERSION:

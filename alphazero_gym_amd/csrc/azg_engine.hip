@@ -157,8 +157,39 @@ void azg_engine_destroy(azg_engine* e) {
     delete e;
 }
 
+// Two HIP runtimes in one process (PyTorch-ROCm wheels bundle their own libamdhip64 under the system library's SONAME; whichever is
+// loaded first serves every library that comes later -- unless the other one was pulled in by path, as `import torch` does):
+// the second one to initialise then finds no GPU or hangs.  Seen from here as two different libamdhip64 files in the process's
+// memory map; reported instead of risking either.  Returns the number of distinct files and their paths.
+static int mapped_hip_runtimes(std::string& paths) {
+    std::vector<std::string> seen;
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return 0;
+    char line[1024];
+    while (fgets(line, sizeof line, f)) {
+        if (!strstr(line, "libamdhip64")) continue;
+        const char* p = strchr(line, '/');
+        if (!p) continue;
+        std::string path(p);
+        while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+        bool dup = false;
+        for (const auto& q : seen) dup = dup || q == path;
+        if (!dup) seen.push_back(path);
+    }
+    fclose(f);
+    paths.clear();
+    for (const auto& q : seen) paths += (paths.empty() ? "" : ", ") + q;
+    return (int)seen.size();
+}
+
 int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(nullptr, AZG_E_INVALID, "null argument");
+    {
+        std::string rts;
+        if (mapped_hip_runtimes(rts) > 1)
+            return fail(nullptr, AZG_E_DEVICE, ("two HIP runtimes are mapped in this process (" + rts + "): load PyTorch (import torch) BEFORE "
+                                               "libazgym_hip.so so that both use PyTorch's copy").c_str());
+    }
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
     if (cfg->env_id < 0 || cfg->env_id > 3) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
@@ -282,7 +313,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     HK(hipMemset(hot, 0, B * R * sizeof(RecL)));
     HK(hipMemset(e->d_carry, 0, B * sizeof(int)));
     P.B = cfg->n_trees; P.n_sims = ns; P.R = e->R; P.Kp = e->Kp; P.A = cfg->num_actions; P.nd = e->nd;
-    P.trace_cap = e->opt.trace_cap > 0 ? e->opt.trace_cap : 4;
+    P.trace_cap = e->opt.trace_cap > 0 ? e->opt.trace_cap : 5;   // (config B on MI355X: 0.484 ms with 1, 0.388 with 3, 0.371 with 5 or 6, 0.43 with 8)
     P.tie_random = cfg->tie_break == AZG_TIE_RANDOM; P.env_id = cfg->env_id; P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
     P.c_uct = cfg->c_uct; P.gamma = cfg->gamma; P.epsilon = cfg->epsilon; P.reward_scale = cfg->reward_scale;
     P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;

@@ -75,7 +75,9 @@ static hipError_t launch(azg_engine* e) {
         else if (e->R <= 511 && nmax < 2048) ts = TS_LDS9;
     }
     if (e->opt.force_global_tree) ts = TS_GLOBAL;
-    if constexpr (HP == 256 && NREG == 1) {
+    // (Continuous mode only.  The discrete family's 8-wave shapes were measured slower than its 4-wave ones -- CartPole, 8192 trees,
+    // 2x256: 1.03 ms against 0.99 ms per search, and they were the only kernels of the family that spilled registers -- and are gone.)
+    if constexpr (HP == 256 && NREG == 1 && ENV != AZG_ENV_CARTPOLE) {
         bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
         if (e->opt.groups == 2) two = true;
         if (e->opt.groups == 1) two = false;

@@ -254,7 +254,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         if (k < P.n_sims) {
             __threadfence_block();
             if (live) tree_phase_b<ENV, TLDS, GMM, TPW>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
-            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_s_setprio(0);   // (after the tree phases on every path, the last step's included)
+        if (k < P.n_sims) {
             __syncthreads();
             first_layer(wt);
             team_arrive(cnt);

@@ -7,8 +7,10 @@
 #include "team.cuh"
 
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
+// wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
+// otherwise it takes whatever the occupancy query allows (up to 6).
 template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB>
-static hipError_t team_launch_form(azg_engine* e) {
+static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     constexpr int NU = HP / 64, TPW = 32 / NU;
     constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
@@ -34,7 +36,7 @@ static hipError_t team_launch_form(azg_engine* e) {
     // blocks that limit is floor(800 / (ceil(sgpr / 16) * 16 + 16)) >= 6 whatever the kernel's sgpr count (<= 112): answers
     // up to 6 are safe to take as they are (and every wait in the kernel is bounded should this ever be wrong)
     int usable = per_cu < 6 ? per_cu : 6;
-    if (usable > MINB) usable = MINB;   // (the form is built for MINB workgroups per CU; the next form takes larger batches)
+    if (wider_form_exists && usable > MINB) usable = MINB;   // (the next form takes the larger batches)
     if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
     hipError_t rc = hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream);
     if (rc != hipSuccess) return rc;
@@ -55,10 +57,11 @@ static hipError_t team_launch_form(azg_engine* e) {
 // then four per CU with short chunks for larger batches (HP = 1024, LDS trees: the shapes that were measured).
 template <int ENV, int HP, bool GMM, int TLDS>
 static hipError_t team_launch(azg_engine* e) {
-    hipError_t rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e);
-    if constexpr (HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV != AZG_ENV_CARTPOLE) {
-        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e);
-        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 4>(e);
+    constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV != AZG_ENV_CARTPOLE;
+    hipError_t rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, WIDE && e->opt.team_wide);
+    if constexpr (WIDE) {
+        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);
+        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 4>(e, false);
     }
     return rc;
 }

@@ -36,13 +36,23 @@ def unpack_replay_rows(rows: torch.Tensor, state_dim: int, K: int):
 
 
 def gather_replay_rows(rows: torch.Tensor, device=None) -> torch.Tensor:
-    """All-gather equally sized per-rank row blocks into [world*B, row] ordered by rank (= by global tree id)."""
+    """All-gather the per-rank row blocks into [B_total, row] ordered by rank (= by global tree id).  The blocks may differ in
+    length (shard_range: by at most one row when B_total is not a multiple of the world size): the lengths are gathered first,
+    shorter blocks are padded to the longest for the collective and the padding is dropped again."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rows
-    rows = rows.to(device) if device is not None else rows
-    out = [torch.empty_like(rows) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, rows.contiguous())
-    return torch.cat(out, dim=0)
+    world = dist.get_world_size()
+    rows = (rows.to(device) if device is not None else rows).contiguous()
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    if rows.shape[0] < longest:
+        rows = torch.cat([rows, rows.new_zeros((longest - rows.shape[0],) + tuple(rows.shape[1:]))], dim=0)
+    out = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(out, rows)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
 def broadcast_weights(model: torch.nn.Module, src: int = 0) -> None:

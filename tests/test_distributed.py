@@ -1,10 +1,11 @@
-"""CPU, world_size 2 over gloo: the N>1 path (tree sharding by global id, replay all-gather, weight broadcast).
+"""CPU, world sizes 2, 4 and 8 over gloo: the N>1 path (tree sharding by global id, replay all-gather, weight broadcast).
 The engine is the oracle test double here; on the GPU box the same code runs over RCCL with the HIP engine."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -27,9 +28,12 @@ def _search(n_trees, base):
 
 
 def _worker(rank, world, port, q):
+    import datetime
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    O.set_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     lo, hi = D.shard_range(B_TOTAL, rank, world)
     roots, r = _search(hi - lo, lo)
     rows = D.pack_replay_rows(roots, r["actions"], r["counts"], r["Q"], r["v_target"])
@@ -58,14 +62,17 @@ def test_shard_range_partitions_every_tree_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_selfplay_equals_single_process():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multi_rank_selfplay_equals_single_process(world):
+    """SURVEY 8e on the CPU double: 10 games over 2, 4 and 8 ranks (4 and 8 do not divide 10: shards of 3/3/2/2 and 2/2/1/.../1
+    games, eight different tree_id_base offsets) -- the gathered replay rows equal the single-process run's row for row."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -126,9 +133,6 @@ def _train_worker(rank, world, port, q, hip=False):
     q.put((rank, hist, float(flat.double().sum()), float(flat.abs().double().sum()), v_engine.tolist(), v_torch.tolist()))
     dist.barrier()
     dist.destroy_process_group()
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.parametrize("hip", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["oracle_double", "hip"])

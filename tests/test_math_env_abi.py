@@ -155,3 +155,35 @@ def test_c_program_runs_a_search_through_the_abi(tmp_path):
     import subprocess
     p = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and "0 trees with a wrong visit total" in p.stdout, (p.stdout[-800:], p.stderr[-800:])
+
+
+def test_loading_the_engine_before_torch_is_reported_not_left_to_hang():
+    """a process that maps a HIP runtime before importing torch (an embedding application loading
+    libazgym_hip.so first) would make `import torch` bring a second libamdhip64 -- torch.cuda then finds no GPU or hangs.
+    _native.lib() raises HipRuntimeConflict instead; the C entry point reports two mapped runtimes through azg_last_error."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys
+sys.path.insert(0, %r)
+from alphazero_gym_amd import _native, _capi
+assert "torch" not in sys.modules
+lib = ctypes.CDLL(_native.LIB_PATH)                     # what an embedding application would do: the engine first
+assert len(_native.mapped_hip_runtimes()) == 1
+try:
+    _native.lib()
+    print("NO ERROR")
+except _native.HipRuntimeConflict as ex:
+    print("CONFLICT", "Import torch before" in str(ex))
+import torch                                            # now the second runtime is mapped as well
+assert len(_native.mapped_hip_runtimes()) == 2
+cfg = _capi.AzgConfig(); cfg.struct_size = ctypes.sizeof(_capi.AzgConfig); cfg.n_trees = 1; cfg.n_sims = 1
+h = ctypes.c_void_p()
+lib.azg_engine_create.restype = ctypes.c_int
+lib.azg_last_error.restype = ctypes.c_char_p
+rc = lib.azg_engine_create(ctypes.byref(cfg), ctypes.byref(h))
+print("CREATE", rc, b"two HIP runtimes" in lib.azg_last_error(None))
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "CONFLICT True" in out.stdout, out.stdout + out.stderr
+    assert "CREATE -3 True" in out.stdout, out.stdout + out.stderr
