@@ -31,7 +31,10 @@ for d in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_insts"):
     for r in csv.DictReader(open(fs[0])):
         if "search_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            # (rocprofv3's VGPR_Count / Accum_VGPR_Count / SGPR_Count columns are dispatch-packet granules, not what the compiler
+            # allocated -- e.g. 216 / 0 for a kernel that holds 256 VGPRs + 171 AGPRs: left out; the compiler's own figures are in
+            # profiles/<round>_resource_usage.txt, written by tools/resource_usage.py)
+            meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size")}
     for k, v in acc.items():
         rows.append(dict(pass_=d, counter=k, launches=len(v), mean_per_launch=sum(v) / len(v), **meta))
 with open(os.path.join(dst, f"{name}_pmc_summary.csv"), "w", newline="") as f:
