@@ -220,9 +220,9 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
 #pragma unroll
                 for (int i = 0; i < NTW; ++i) h[g][i] = act4<NREG == 0>(P.act, acc[g][i]);
             STAMP(m2b);
-            if (l == 0) { STAMP_ADD(4, m0, m1); }
-            STAMP_ADD(5, m1, m2);
-            STAMP_ADD(6, m2, m2b);
+            if (l == 0) { STAMP_M_ADD(4, m0, m1); }
+            STAMP_M_ADD(5, m1, m2);
+            STAMP_M_ADD(6, m2, m2b);
             f32x4* t = buf; buf = other; other = t;
         }
     } else {

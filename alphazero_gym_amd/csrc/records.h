@@ -134,9 +134,23 @@ struct LockStep {
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
 #define STAMP_PARAM , unsigned long long* st_acc
 #define STAMP_ARG , st_acc
+#ifdef AZG_STAMPS_A   /* slots 4..6 = phase A's parts (finish leaf | backup | re-scoring) instead of the network's */
+#define STAMP_A(var) STAMP(var)
+#define STAMP_A_ADD(slot, t0, t1) do { if (st_acc) st_acc[slot] += (t1) - (t0); } while (0)
+#define STAMP_M_ADD(slot, t0, t1)
+#else
+#define STAMP_A(var)
+#define STAMP_A_ADD(slot, t0, t1)
+#define STAMP_M_ADD(slot, t0, t1) STAMP_ADD(slot, t0, t1)
+#endif
+#define STAMP_PARAM_OPT , unsigned long long* st_acc = nullptr
 #else
 #define STAMP_PARAM
 #define STAMP_ARG
 #define STAMP(var)
 #define STAMP_ADD(slot, t0, t1)
+#define STAMP_A(var)
+#define STAMP_A_ADD(slot, t0, t1)
+#define STAMP_M_ADD(slot, t0, t1)
+#define STAMP_PARAM_OPT
 #endif

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
         }
         if constexpr (!MULTI) {
             // ================= tree phase A: finish the evaluated leaf, back up =================
-            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
             if (sim == P.n_sims - 1) break;
             __threadfence_block();
             STAMP(t_d);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             int k = 0;
             while (run) {
                 STAMP(t_c2);
-                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt);
+                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
                 __threadfence_block();
                 STAMP(t_d);
                 st.need_eval = false;

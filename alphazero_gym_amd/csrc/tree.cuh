@@ -227,11 +227,13 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 // (fetched while descending), so nothing is loaded from global memory here.  Paths deeper than 16 finish in backup_from.
 // On return pW holds the slot's updated W and `rec` the slot's updated record (zeros in lanes without a slot); `chainR` is the
 // lane's return of this trace.  same_chain: the trace is the previous one again (same path, same terminal leaf, see
-// tree_phase_b): every lane's return is the one it had, the serial chain is skipped.
+// tree_phase_b): every lane's return is the one it had, the serial chain is skipped.  r_uniform (discrete mode): the reward every
+// edge carries (env.cuh: discrete_env_reward) -- equal to pr in every lane that holds a slot.
 template <bool CONT, int TLDS, typename F>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
                                             double gamma, int D, int my_depth, int pid, double pr, double& pW, F&& on_node,
-                                            typename TreeStore<TLDS>::Rec& rec, double& chainR, bool same_chain = false) {
+                                            typename TreeStore<TLDS>::Rec& rec, double& chainR, bool same_chain = false,
+                                            double r_uniform = 0.0) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
@@ -239,6 +241,19 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
     // value (lane sub + 1, the slot of depth + 1) and adds its own reward -- the same serial chain, no LDS shuffles
     if (same_chain) {
         myR = chainR;
+    } else if constexpr (!CONT) {
+        // discrete mode: every edge of the path carries the same reward (r_uniform), so the chain R_0 = r + gamma V, R_d = r + gamma R_{d-1}
+        // needs nothing from the other lanes: every lane runs it by itself (two dependent float64 operations per level instead of
+        // a DPP round trip) and keeps the value of its own slot -- the same operations in the same order as the travelling form
+        double R = 0.0;
+#pragma unroll 2
+        for (int d = 0; d < n0; ++d) {
+            const double gR = d == 0 ? gamma * (double)V : gamma * R;
+            R = r_uniform + gR;
+            if (sub == ((D - d) & 15)) myR = R;
+        }
+        Rv = R;            // (D >= 16: the return of the shallowest of the 16 levels, handed to backup_from)
+        chainR = myR;
     } else {
 #pragma unroll 1
         for (int d = 0; d < n0; ++d) {
@@ -249,7 +264,7 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
         }
         chainR = myR;
     }
-    if (D >= 16) Rv = __shfl(myR, (D - 15) & 15, 16);
+    if (CONT && D >= 16) Rv = __shfl(myR, (D - 15) & 15, 16);
     const bool valid = my_depth >= 0 && my_depth > D - 16;
     int par = 0;
     rec = make_edge<Rec>(0.0, 0);

@@ -210,10 +210,11 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
-                                             const float* bhead, const double* s_sqrt) {
+                                             const float* bhead, const double* s_sqrt STAMP_PARAM_OPT) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
+    STAMP_A(ta0);
     if (st.need_eval) {
         // discrete mode: outputs 0..3 (value, logits) in one pass over the partials; continuous mode keeps three separate
         // sums (measured at config C: the one-pass form is 3 % slower there, at config B 10 % faster)
@@ -302,13 +303,18 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
             }
         }
     }
+    STAMP_A(ta1);
+    STAMP_A_ADD(4, ta0, ta1);   // finish leaf
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
         const bool keep = !CONT && P.epsilon == 0.0 && !P.tie_random;   // (cached selections: discrete mode, see rec_best)
         Rec myrec;
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
                                 [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); }, myrec, st.chainR,
-                                RESUME && !CONT && st.repeat);   // (only the kernels that resume descents set st.repeat)
+                                RESUME && !CONT && st.repeat,    // (only the kernels that resume descents set st.repeat)
+                                CONT ? 0.0 : discrete_env_reward(P.env_id));
+        STAMP_A(ta2);
+        STAMP_A_ADD(5, ta1, ta2);   // backup (return chain, record updates)
         if constexpr (!CONT) {
             if (keep) {
                 // the selections of the path's nodes, with their new statistics: depths D-1 .. max(0, D-15) are in the lanes' slots
@@ -334,6 +340,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 }
             }
         }
+        STAMP_A(ta3);
+        STAMP_A_ADD(6, ta2, ta3);   // re-scoring of the path's nodes + where the next descent leaves the path
     }
 }
 

@@ -7,7 +7,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "libazgym_hip_stamp.so")
+PHASE_A = "--phase-a" in sys.argv   # slots 4..6 = phase A's parts (libazgym_hip_stampa.so) instead of the network's
+if PHASE_A:
+    sys.argv.remove("--phase-a")
+os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "libazgym_hip_stampa.so" if PHASE_A else "libazgym_hip_stamp.so")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
@@ -50,7 +53,9 @@ def main():
         v = buf[:, i].astype(np.float64)
         print(f"{nm:24s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step  ({100 * v.mean() / tot:5.1f} %)  min {v.min() / (n_sims + 1):8.0f} max {v.max() / (n_sims + 1):8.0f}")
     print(f"total {tot / (n_sims + 1):.0f} shader cycles/step")
-    for i, nm in ((4, "  mlp: layer0+ELU+publish"), (5, "  mlp: hidden MFMA loop"), (6, "  mlp: hidden act + store")):
+    sub = ((4, "  A: finish leaf"), (5, "  A: backup (chain + records)"), (6, "  A: re-scoring + resume")) if PHASE_A else \
+          ((4, "  mlp: layer0+ELU+publish"), (5, "  mlp: hidden MFMA loop"), (6, "  mlp: hidden act + store"))
+    for i, nm in sub:
         v = buf[:, i].astype(np.float64)
         print(f"{nm:28s} mean {v.mean() / (n_sims + 1):9.0f} cycles/step")
     b = buf.astype(np.float64)
