@@ -263,7 +263,7 @@ def kernel_name(eng):
 
 
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md)
-B_KERNEL = "search_kernel<0, 128, 1, 1, false, 4, 1, 8>"   # what config B is expected to run as (the engine reports what it did run)
+B_KERNEL = "search_kernel<0, 128, 1, 1, false, 4, 1, 16>"   # what config B is expected to run as (the engine reports what it did run)
 
 
 def tree_walk_bytes(dump, n_actions, n_sims):
