@@ -27,6 +27,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
     unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)u), hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(u >> 32));
     return azg_u2d(((unsigned long long)hi << 32) | lo);
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+#define DPP_QUAD_BCAST1 0x55   // quad_perm:[1,1,1,1]
 #define DPP_QUAD_XOR1 0xB1   // quad_perm:[1,0,3,2]
 #define DPP_QUAD_XOR2 0x4E   // quad_perm:[2,3,0,1]
 #define DPP_ROW_ROR4 0x124

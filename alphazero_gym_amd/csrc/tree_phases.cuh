@@ -258,15 +258,25 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
             const int A = P.A;
             // (logits 1 .. 3 come with out4; further actions, should an environment have them, through head_output)
-            auto logit = [&](int a) { return a == 0 ? out4.y : (a == 1 ? out4.z : (a == 2 ? out4.w : head_output<NCH, PSTR>(parts, bhead, tl, 1 + a))); };
-            float mx = logit(0);
-            for (int a = 1; a < A; ++a) { float v = logit(a); mx = v > mx ? v : mx; }
-            float sum = 0.0f, e_mine = 0.0f;   // e_mine: exp(logit - max) of the lane's own action (lanes 0 .. A-1)
-            for (int a = 0; a < A; ++a) {
-                const float e = azg_expf(logit(a) - mx);
-                sum = sum + e;
-                if (sub == a) e_mine = e;
+            // lane a < A works on action a: its logit, its exp; the maximum and the sum are taken in action order (the sum as
+            // ((0 + e_0) + e_1) + ..., the reference's order) from the lanes' values
+            float my_logit = sub == 0 ? out4.y : (sub == 1 ? out4.z : out4.w);
+            if (A > 3 && sub >= 3 && sub < A) my_logit = head_output<NCH, PSTR>(parts, bhead, tl, 1 + sub);
+            float mx = out4.y;
+            if (A == 2) {
+                mx = out4.z > mx ? out4.z : mx;
+            } else {
+                for (int a = 1; a < A; ++a) { const float v = __shfl(my_logit, a, 16); mx = v > mx ? v : mx; }
             }
+            const float e_mine = azg_expf(my_logit - mx);   // (lanes >= A: an unused value)
+            float sum;
+            if (A == 2) {
+                sum = dpp_f32<DPP_QUAD_BCAST0>(e_mine) + dpp_f32<DPP_QUAD_BCAST1>(e_mine);   // 0 + e_0 is e_0 exactly
+            } else {
+                sum = 0.0f;
+                for (int a = 0; a < A; ++a) sum = sum + __shfl(e_mine, a, 16);
+            }
+            // (two-action form: only the first quad's lanes hold the sum; only lanes 0 .. A-1 use it)
             int k0 = st.nrec;
             st.nrec += A;
             if (sub < A) {
