@@ -425,6 +425,9 @@ def main():
     from alphazero_gym_amd import _capi, _native
     from alphazero_gym_amd.synthetic import make_weights
 
+    if dist is not None and os.environ.get("AZG_BENCH_DIE_RANK") == str(rank):
+        os._exit(3)   # (test hook, tests/test_bench.py: a rank that dies after the rendezvous must fail the run, not hang it)
+
     B = args.trees
     desc, blob = _capi.make_desc(3, HIDDEN, 2, "elu"), make_weights(34, 3, HIDDEN, 2)
     eng = _native.HipEngine(n_trees=B, n_sims=N_SIMS, tree_id_base=rank * B, device_id=dev, **PENDULUM)

@@ -39,6 +39,22 @@ def test_multi_rank_loop_on_one_gpu():
     assert "config D" in out["config"]["workload"]
 
 
+@pytest.mark.gpu
+def test_a_dead_rank_fails_the_run_instead_of_hanging_it():
+    """one of two ranks exits right after the rendezvous (AZG_BENCH_DIE_RANK, a test hook).  The survivor's
+    collectives are bounded (--dist-timeout) and torch.distributed.run tears the job down: bench.py exits non-zero, well inside
+    the test's own time limit, and prints no JSON line."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AZG_BENCH_DIE_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--trees", "256",
+                        "--backend", "gloo", "--same-device", "--dist-timeout", "30", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 300
+
+
 def _bench_json(args, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
