@@ -154,7 +154,9 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     constexpr bool MULTI = !CONT;
     int my_sim = -1;                    // the trace whose leaf is pending (-1: the root's evaluation); n_sims: the tree is done
     const int n_live = (P.B - (int)blockIdx.x * TPW) < TPW ? (P.B - (int)blockIdx.x * TPW) : TPW;
-    for (int sim = -1; MULTI || sim < P.n_sims; ++sim) {
+    // (every unfinished tree completes at least one trace per step, so n_sims + 1 steps always suffice: the bound is a guard, the
+    // discrete kernels normally leave through s_done long before)
+    for (int sim = -1; sim < P.n_sims; ++sim) {
         // ================= network phase: evaluate the pending leaves =================
         STAMP(t_a);
         // one barrier: the observations of phase B are visible.  The network runs even if every pending leaf of the workgroup is
