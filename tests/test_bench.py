@@ -25,16 +25,20 @@ def test_gpus_must_match_world_size():
 
 
 @pytest.mark.gpu
-def test_multi_rank_loop_on_one_gpu():
-    """`python bench.py --gpus 2` spawns its own ranks; config D's step (self-play step, all-gather of the step's rows, weight
-    broadcast + engine re-sync) runs with gloo and both ranks on GPU 0."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_multi_rank_loop_on_one_gpu(ranks):
+    """`python bench.py --gpus N` spawns its own ranks; config D's step (self-play step, all-gather of the step's rows, weight
+    broadcast + engine re-sync) runs with gloo and every rank on GPU 0 (N = 2 and 4: four tree_id_base offsets, four-way gather).
+    The N > 1 line carries the CPU baseline and a note about the traffic figure."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--trees", "512",
-                        "--bcast-every", "2", "--backend", "gloo", "--same-device"], env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--trees", "512",
+                        "--bcast-every", "2", "--backend", "gloo", "--same-device"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert out["n_gpus"] == ranks and out["steps"] == 5 and out["scaling"] == "weak"
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"
+    assert "traffic_note" in out["roofline"]
     assert out["value"] > 0 and out["extra"]["search_only"]["sims_per_s"] >= out["value"] * 0.5
     assert "config D" in out["config"]["workload"]
 

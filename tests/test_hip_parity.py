@@ -461,6 +461,42 @@ def test_shard_invariance_on_the_device(native, cfg):
                     np.testing.assert_array_equal(x[lo:lo + 2048], y)
 
 
+@pytest.mark.parametrize("cfg", ["D", "E"])
+def test_last_rank_of_an_8_gpu_job(native, cfg):
+    """The N = 8 configurations that no single box can run whole (BASELINE configs D: 32768 games, and E: 8192 trees of the 4x1024
+    network, sharded over 8 GPUs): the leg of the LAST rank -- global tree ids 7 * B/8 ... B - 1 through `tree_id_base`, exactly as
+    bench.py and distributed.shard_range set it up -- on this one GPU, against the oracle given the same global ids.  Synthetic
+    roots, noise streams and results are keyed by the global id, so this is the same computation rank 7 of the real job runs."""
+    from alphazero_gym_amd import distributed as D
+    if cfg == "D":
+        total, hidden = 32768, [256, 256]
+    else:
+        total, hidden = 8192, [1024] * 4
+    lo, hi = D.shard_range(total, 7, 8)
+    assert (lo, hi) == (7 * total // 8, total)
+    kw = dict(env_id=2, mode=1, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34, n_trees=hi - lo, tree_id_base=lo)
+    desc, blob = _capi.make_desc(3, hidden, 2, "elu"), O.make_weights(34, 3, hidden, 2)
+    e = native.HipEngine(**kw)
+    roots = e.synthetic_roots()
+    e.set_weights(desc, blob)
+    e.search(roots)
+    r, d = e.results(), e.dump_tree()
+    e.close()
+    assert (r["counts"].sum(1) == 200).all()
+    n = 512 if cfg == "D" else 128                                  # the shard's last trees against the oracle (all of them take minutes on the host)
+    okw = dict(kw, n_trees=n, tree_id_base=hi - n)
+    o = O.OracleEngine(**okw)
+    np.testing.assert_array_equal(o.synthetic_roots(), roots[-n:])
+    o.set_weights(desc, blob)
+    o.search(roots[-n:])
+    ro, do = o.results(), o.dump_tree()
+    o.close()
+    for k in ro:
+        np.testing.assert_array_equal(ro[k], r[k][-n:], err_msg=k)
+    for k in do:
+        np.testing.assert_array_equal(do[k], d[k][-n:], err_msg=k)
+
+
 def _random_case(rng):
     """A random engine configuration + network: every mode, width class, activation, head and search parameter."""
     cont = rng.random() < 0.5
