@@ -107,12 +107,12 @@ def clean_child_env():
     return env
 
 
-def live_traffic(trees, config="C", kernel="search_kernel"):
-    """HBM bytes per launch of the search kernel measured NOW: two child runs of this script's --traffic-probe under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one), values in KiB per
-    dispatch, the read side doubled (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM section -- an
-    upper bound for this kernel's narrow reads).  The children are started as ordinary child processes from /tmp with
-    TMPDIR=/tmp; the program after `--` is the interpreter itself.  (bytes, None) or (None, reason)."""
+def live_counters(trees, config, kernel, passes):
+    """Hardware counters of `kernel` measured NOW: one child run of this script's --traffic-probe per entry of `passes` (a list of
+    counter-name lists: counters that do not fit one pass go into separate ones) under `rocprofv3 --pmc`, averaged over the
+    kernel's launches but the first (which also pulls the weights and tables in).  The children are started as ordinary child
+    processes from /tmp with TMPDIR=/tmp and an environment without anything a profiler left behind; the program after `--` is the
+    interpreter binary itself.  ({counter: mean per launch}, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -132,27 +132,47 @@ def live_traffic(trees, config="C", kernel="search_kernel"):
     out = {}
     work = tempfile.mkdtemp(prefix="azg_traffic_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(work, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__), "--traffic-probe",
-                   "--trees", str(trees), "--probe-config", config]
+        for n, counters in enumerate(passes):
+            d = os.path.join(work, f"pass{n}")
+            cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__), "--traffic-probe",
+                                                     "--trees", str(trees), "--probe-config", config]
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=clean_child_env(), capture_output=True, text=True, timeout=240)
             except subprocess.TimeoutExpired:
-                return None, f"rocprofv3 --pmc {counter} timed out"
+                return None, f"rocprofv3 --pmc {' '.join(counters)} timed out"
             if p.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} exited with {p.returncode}"
-            vals = []
+                return None, f"rocprofv3 --pmc {' '.join(counters)} exited with {p.returncode}"
+            vals = {c: [] for c in counters}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                        vals.append(float(r["Counter_Value"]))
-            if len(vals) < 2:
-                return None, f"no {counter} rows for {kernel}"
-            out[counter] = float(np.mean(vals[1:]))          # (the first launch also pulls the weights and tables in)
+                    if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") in vals:
+                        vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for c in counters:
+                if len(vals[c]) < 2:
+                    return None, f"no {c} rows for {kernel}"
+                out[c] = float(np.mean(vals[c][1:]))
     finally:
         shutil.rmtree(work, ignore_errors=True)
+    return out, None
+
+
+def live_traffic(trees, config="C", kernel="search_kernel"):
+    """HBM bytes per launch of the search kernel measured NOW: FETCH_SIZE and WRITE_SIZE in separate passes (the two do not fit
+    one), values in KiB per dispatch, the read side doubled (gfx950 tallies 128-byte read requests at 64 bytes:
+    MI355X_MICROARCH.md, HBM section -- an upper bound for this kernel's narrow reads).  (bytes, None) or (None, reason)."""
+    out, why = live_counters(trees, config, kernel, [["FETCH_SIZE"], ["WRITE_SIZE"]])
+    if out is None:
+        return None, why
     return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, None
+
+
+def live_mfma_busy(trees, config="C", kernel="search_kernel"):
+    """Share of the launch during which the matrix pipes were busy, from the hardware: SQ_VALU_MFMA_BUSY_CYCLES (summed over the
+    SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs).  (fraction, None) or (None, reason)."""
+    out, why = live_counters(trees, config, kernel, [["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]])
+    if out is None:
+        return None, why
+    return out["SQ_VALU_MFMA_BUSY_CYCLES"] / (out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), None
 
 
 def physical_cores():
@@ -354,6 +374,11 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, f
             tnote = f"live PMC passes unavailable ({why}); from the committed passes ({src})"
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_note"] = tnote
+        if not hbm:   # (the MFMA-bound configuration: the hardware's own account of how busy the matrix pipes were)
+            busy, why = live_mfma_busy(trees, live[0], live[1])
+            out["roofline"]["mfma_busy"] = busy
+            out["roofline"]["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), one more rocprofv3 --pmc child pass"
+                                                 if busy is not None else f"not measured ({why})")
     if hbm:
         out["roofline_hbm"] = hbm_block(*walk, trees, n_sims, med, traffic, tnote)
     return out
@@ -610,6 +635,12 @@ def main():
             if traffic is None and B == N_TREES:
                 traffic, src = profiled_traffic()
                 traffic_note += f"; from the committed passes ({src})"
+            if not args.no_live_traffic:
+                busy, why = live_mfma_busy(B)
+                extra["mfma_busy"] = ({"value": busy, "note": "hardware view of roofline.frac: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the "
+                                                               "search kernel, one more rocprofv3 --pmc child pass of this run (it also counts the first layer's "
+                                                               "and the heads' MFMAs, which the 134 144-FLOP figure leaves out)"}
+                                      if busy is not None else {"value": None, "note": f"not measured ({why})"})
         out = {
             "metric": "MCTS sims/sec (whole node), Pendulum-v1 4096 trees n_sims=200, 1/2/4/8 GPU", "value": sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
