@@ -598,8 +598,15 @@ def _t3_scale_chunk(job):
     reference's DiagonalNormalPolicy; 'b': CartPole discrete with its DiscretePolicy)."""
     kind, hidden, n_rollouts, lo, hi, roots, seed = job
     torch.set_num_threads(1)
-    cont = kind != "b"
-    if cont:
+    cont = kind not in ("b", "d")
+    gmm = kind == "g"           # the reference's default continuous policy: 2-component mixture (config/policy/ContinuousPolicy.yaml)
+    eps = 0.1 if kind == "d" else 0.0   # the reference's default discrete search: epsilon-greedy 0.1 (config/mcts/MCTSDiscrete.yaml)
+    if gmm:
+        blob = O.make_weights(35, 3, hidden, 6)
+        pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                          num_components=2, action_bound=2.0)
+        set_policy_weights(pol, blob, 3, hidden, 6)
+    elif cont:
         blob = O.make_weights(34, 3, hidden, 2)
         pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
                           num_components=1, action_bound=2.0)
@@ -610,20 +617,35 @@ def _t3_scale_chunk(job):
                           num_actions=2)
         set_policy_weights(pol, blob, 4, hidden, 2)
     res = []
-    orig_normal = torch.normal
+    orig_normal, orig_multinomial, orig_random = torch.normal, torch.multinomial, RM.random
     log, orig_bp, traced = _leaf_log()
     RM.MCTS.backprop = traced
     TIES["n"] = 0
+    margins = []
     try:
         for ti in range(lo, hi):
             state = {"n": 0}
 
             def fake_normal(mean, std, *a, **k):
+                if not gmm:
+                    state["n"] += 1        # one widening record per sample_action call (mixture: counted by fake_multinomial)
+                noise = O.normal(seed, ti, 0, state["n"])
+                return mean + std * np.float32(noise)
+
+            def fake_multinomial(probs, num_samples, replacement=False, **k):
+                # MixtureSameFamily.sample (policies.py:656-668): component by inverse CDF with the engine's uniform of the record
                 state["n"] += 1
-                eps = O.normal(seed, ti, 0, state["n"])
-                return mean + std * np.float32(eps)
+                u = np.float32(O.gmm_u(seed, ti, 0, state["n"]))
+                cum = np.cumsum(probs.detach().numpy().astype(np.float32), axis=-1, dtype=np.float32)
+                margins.append(float(np.min(np.abs(cum[..., :-1] - u))))
+                idx = (u >= cum[..., :-1]).sum(-1)
+                return torch.as_tensor(idx, dtype=torch.long).reshape(probs.shape[:-1] + (1,))
 
             torch.normal = fake_normal
+            if gmm:
+                torch.multinomial = fake_multinomial
+            if eps:
+                RM.random = EngineRandom(seed, ti, 0)
             COUNTER["n"] = 0
             del log[:]
             if cont:
@@ -632,15 +654,16 @@ def _t3_scale_chunk(job):
                                       V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
             else:
                 env = CartPoleEnv(state=roots[ti - lo])
-                m = RM.MCTSDiscrete(model=pol, num_actions=2, n_rollouts=n_rollouts, c_uct=1.5, gamma=1, epsilon=0.0,
+                m = RM.MCTSDiscrete(model=pol, num_actions=2, n_rollouts=n_rollouts, c_uct=1.5, gamma=1, epsilon=eps,
                                     V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
             m.search(env)
             s, actions, counts, Q, V = m.return_results("max_visit")
             res.append((np.asarray(counts, np.int32).reshape(-1), np.array([np.asarray(q).reshape(-1)[0] for q in Q], np.float64),
                         np.asarray(actions, np.float32).reshape(-1), float(np.asarray(V).reshape(-1)[0]), np.array(log, np.int32)))
     finally:
-        torch.normal = orig_normal
+        torch.normal, torch.multinomial, RM.random = orig_normal, orig_multinomial, orig_random
         RM.MCTS.backprop = orig_bp
+    assert not margins or min(margins) > 1e-6, min(margins)   # no component pick sits on a boundary of the cumulative mixture weights
     return lo, res, TIES["n"]
 
 
@@ -648,6 +671,10 @@ T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engi
     "c": (2, 1, [256, 256], "elu", 200, 4096, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
     "b": (0, 0, [128, 128], "relu", 100, 4096, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
     "e": (2, 1, [1024] * 4, "elu", 200, 128, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
+    # the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): 2-component mixture head on a 3x128 ELU
+    # trunk with 25 rollouts; 2x128 ReLU with 8 rollouts and epsilon-greedy 0.1 (draws: the engine's, injected as `random`)
+    "g": (2, 1, [128, 128, 128], "elu", 25, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
+    "d": (0, 0, [128, 128], "relu", 8, 1024, dict(c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1)),
 }
 T3_SCALE_FULL = 1024   # trees per leg whose Q / actions / value target are stored as well (visit counts: every tree)
 
@@ -664,8 +691,9 @@ def run_t3_scale(procs=8):
     for tag, (env_id, mode, hidden, act, n_roll, B, kw) in T3_SCALE.items():
         eng = O.OracleEngine(env_id=env_id, mode=mode, n_trees=B, n_sims=n_roll, seed=34, **kw)
         roots = eng.synthetic_roots()
-        n_dist = 2
-        eng.set_weights(_capi.make_desc(4 if mode == 0 else 3, hidden, n_dist, act), O.make_weights(34, 4 if mode == 0 else 3, hidden, n_dist))
+        n_dist = 6 if tag == "g" else 2
+        eng.set_weights(_capi.make_desc(4 if mode == 0 else 3, hidden, n_dist, act, num_components=2 if tag == "g" else 0),
+                        O.make_weights(35 if tag == "g" else 34, 4 if mode == 0 else 3, hidden, n_dist))
         eng.trace_enable()
         eng.search(roots)
         ro = eng.results()

@@ -1,14 +1,16 @@
 """Tier T3 at BASELINE scale (VERDICT r03 row g): visit-count parity with the reference run END TO END -- the reference's
 MCTSContinuous.search / MCTSDiscrete.search (alphazero/search/mcts.py:418-462, 656-702) with its REAL torch policies
 (alphazero/network/policies.py:340-352, 436-499) -- on the engine's own synthetic roots of configs C (all 4096 trees, 2x256 ELU,
-200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU, 200 rollouts):
+200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
+each -- of the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): the 2-component mixture head on a
+3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`):
 tests/golden/t3_scale.npz, written by tests/golden/gen_golden.py `scale` from the imported reference.
 
 The networks differ from torch's by ~1e-7 (summation order), so a selection whose two best scores are closer than that could
 legitimately flip.  The test therefore reports a MATCH RATE and attributes every mismatching tree: the fixture holds, for the trees
 whose counts differed from the oracle's when it was generated, the reference's per-trace leaf records; the test finds the first
 trace at which the oracle leaves the reference's sequence and requires the oracle's tightest arg-max gap on that trace to be below
-1e-6 (a near-tie) -- anything else is a real difference and fails.  (When this fixture was generated: 1 mismatching tree of 8320 -- config C's tree 1815 leaves the reference's sequence at trace 24,
+1e-6 (a near-tie) -- anything else is a real difference and fails.  (When this fixture was generated: 1 mismatching tree of 10368 -- config C's tree 1815 leaves the reference's sequence at trace 24,
 where the oracle's two best scores are 2.07e-8 apart.)
 """
 import os
@@ -23,11 +25,22 @@ from alphazero_gym_amd import _capi
 TOL = 1e-5          # north_star: Q-values / policy outputs within 1e-5
 NEAR_TIE = 1e-6     # a selection whose best two scores are closer than this may flip under a ~1e-7 network difference
 
-LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims)
-    "c": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [256, 256], "elu", 200),
-    "b": (dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, seed=34), 4, [128, 128], "relu", 100),
-    "e": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [1024] * 4, "elu", 200),
+LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims, network outputs besides the value, mixture components, weight seed)
+    "c": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [256, 256], "elu", 200, 2, 0, 34),
+    "b": (dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, seed=34), 4, [128, 128], "relu", 100, 2, 0, 34),
+    "e": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [1024] * 4, "elu", 200, 2, 0, 34),
+    # the reference's own default configurations (config/mcts/*.yaml, config/policy/*.yaml): mixture head, 25 rollouts; epsilon-greedy 0.1, 8 rollouts
+    "g": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [128, 128, 128], "elu", 25, 6, 2, 35),
+    "d": (dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1, seed=34), 4, [128, 128], "relu", 8, 2, 0, 34),
 }
+N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024
+NAMES = {"c": "config C", "b": "config B", "e": "config E", "g": "the reference's default continuous setup (mixture head, 25 rollouts)",
+         "d": "the reference's default discrete setup (epsilon-greedy 0.1, 8 rollouts)"}
+
+
+def _network(leg):
+    kw, in_dim, hidden, act, n_sims, n_dist, ncomp, wseed = leg
+    return _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp), O.make_weights(wseed, in_dim, hidden, n_dist)
 
 
 def first_divergence(ref_leaf, own_leaf):
@@ -37,10 +50,11 @@ def first_divergence(ref_leaf, own_leaf):
     return int(d[0]) if d.size else -1
 
 
-def attribute(tag, tree, ref_leaf, kw, in_dim, hidden, act, n_sims, root):
+def attribute(tag, tree, ref_leaf, root):
     """Re-search one tree on the oracle with trace diagnostics; (first diverging trace, the oracle's tightest arg-max gap on it)."""
+    kw, n_sims = LEGS[tag][0], LEGS[tag][4]
     o = O.OracleEngine(n_trees=1, n_sims=n_sims, tree_id_base=int(tree), **kw)
-    o.set_weights(_capi.make_desc(in_dim, hidden, 2, act), O.make_weights(34, in_dim, hidden, 2))
+    o.set_weights(*_network(LEGS[tag]))
     o.trace_enable()
     o.search(root[None, :])
     leaf, margin = o.trace_get()
@@ -49,17 +63,17 @@ def attribute(tag, tree, ref_leaf, kw, in_dim, hidden, act, n_sims, root):
     return d, (float(margin[0, d]) if d >= 0 else float("inf"))
 
 
-def _scale(engine_cls, legs=("c", "b", "e")):
+def _scale(engine_cls, legs=("c", "b", "e", "g", "d")):
     z = np.load(os.path.join(P.GOLDEN, "t3_scale.npz"))
     total = matched = 0
     lines = []
     for tag in legs:
-        kw, in_dim, hidden, act, n_sims = LEGS[tag]
+        kw, n_sims = LEGS[tag][0], LEGS[tag][4]
         roots = z[f"{tag}_roots"]
         B = len(roots)
         e = engine_cls(n_trees=B, n_sims=n_sims, **kw)
         np.testing.assert_array_equal(e.synthetic_roots(), roots)      # the fixture's roots are the engine's own synthetic roots 0..B-1
-        e.set_weights(_capi.make_desc(in_dim, hidden, 2, act), O.make_weights(34, in_dim, hidden, 2))
+        e.set_weights(*_network(LEGS[tag]))
         e.search(roots)
         r = e.results()
         e.close()
@@ -72,7 +86,7 @@ def _scale(engine_cls, legs=("c", "b", "e")):
             # a tree that differs from the reference must be one the generator saw differing on the oracle too (HIP == oracle bit
             # for bit), and its first diverging trace must sit on a near-tie of the oracle's scores
             assert int(t) in known, f"{tag} tree {t}: visit counts differ from the reference's: {r['counts'][t][:K]} vs {ref_counts[t]}"
-            d, gap = attribute(tag, t, z[f"{tag}_mismatch_ref_leaf"][known[int(t)]], kw, in_dim, hidden, act, n_sims, roots[t])
+            d, gap = attribute(tag, t, z[f"{tag}_mismatch_ref_leaf"][known[int(t)]], roots[t])
             assert d >= 0 and gap < NEAR_TIE, f"{tag} tree {t}: first diverging trace {d} with an arg-max gap of {gap:.3e}: not a near-tie"
             lines.append(f"   {tag} tree {t}: leaves the reference at trace {d}, arg-max gap {gap:.3e} (near-tie)")
         # Q / actions / value target of the stored trees that match
@@ -87,7 +101,7 @@ def _scale(engine_cls, legs=("c", "b", "e")):
         # the selected action index (max visit count, first index: agents.py:524-527) follows from identical counts
         total += B
         matched += int(same.sum())
-        lines.append(f"T3 scale, config {tag.upper()}: {int(same.sum())} of {B} trees have the reference's visit counts "
+        lines.append(f"T3 scale, {NAMES[tag]}: {int(same.sum())} of {B} trees have the reference's visit counts "
                      f"(match rate {same.mean():.4f}); Q / actions / value target within {TOL} on the {len(ok)} stored trees")
     lines.append(f"T3 scale, all legs: visit-count match rate {matched}/{total} = {matched / total:.4f} ({engine_cls.__name__})")
     print("\n" + "\n".join(lines))
@@ -96,7 +110,7 @@ def _scale(engine_cls, legs=("c", "b", "e")):
 
 def test_oracle_matches_reference_with_torch_policy_at_baseline_scale():
     matched, total = _scale(O.OracleEngine)
-    assert total == 4096 + 4096 + 128
+    assert total == N_TREES_ALL
     assert matched / total >= 0.999    # (every mismatch has already been attributed to a near-tie above)
 
 
@@ -105,7 +119,7 @@ def test_hip_matches_reference_with_torch_policy_at_baseline_scale(capsys):
     from alphazero_gym_amd import _native
     _native.lib()
     matched, total = _scale(_native.HipEngine)
-    assert total == 4096 + 4096 + 128
+    assert total == N_TREES_ALL
     assert matched / total >= 0.999
     with capsys.disabled():   # the rate belongs in the GPU run's log
         print(f"\n[T3 scale on HIP] visit-count match rate vs the reference with its torch policies: {matched}/{total} = {matched / total:.4f}")
@@ -116,7 +130,7 @@ def test_first_divergence_and_trace_diagnostics():
     definite trace; before it every leaf is identical, and the reported gap is the smallest arg-max gap met on that trace."""
     assert first_divergence([1, 2, 3], [1, 2, 3]) == -1
     assert first_divergence([1, 2, 3], [1, 5, 3]) == 1
-    kw, in_dim, hidden, act, n_sims = LEGS["c"]
+    kw, in_dim, hidden, act, n_sims = LEGS["c"][:5]
     w = O.make_weights(34, in_dim, hidden, 2)
     leaves = []
     for scale in (1.0, 1.0 + 2e-3):
