@@ -65,6 +65,39 @@ def test_selfplay_hip_matches_oracle_bit_for_bit(case):
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["config_D_leg", "cartpole_4096"])
+def test_selfplay_at_baseline_size_hip_matches_oracle(which):
+    """The device-resident self-play step at BASELINE size -- config D's per-GPU leg (Pendulum-v1, 4096 games, 200 simulations per
+    move, 2x256 ELU; tree ids of rank 3 of 8) and CartPole with config B's search (4096 games, 100 simulations, 2x128 ReLU; several
+    traces per step, episodes ending and restarting inside the window): every replay row of every game and step, the episode
+    statistics and the games' env states identical to the oracle's, bit for bit."""
+    from alphazero_gym_amd import _native
+    if which == "config_D_leg":
+        kw = dict(env_id=2, mode=1, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34, tree_id_base=3 * 4096)
+        desc, steps, max_len = (3, [256, 256], 2, "elu"), 3, 2
+    else:
+        kw = dict(env_id=0, mode=0, n_sims=100, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+        desc, steps, max_len = (4, [128, 128], 2, "relu"), 6, 4
+    out = []
+    for cls in (_native.HipEngine, O.OracleEngine):
+        e = cls(n_trees=4096, **kw)
+        in_dim, hidden, nd, act = desc
+        e.set_weights(_capi.make_desc(in_dim, hidden, nd, act), O.make_weights(34, in_dim, hidden, nd))
+        e.selfplay_begin(max_len, False, capacity_steps=steps)
+        for _ in range(steps):
+            e.selfplay_step()
+        out.append((e.selfplay_rows(clear=True), e.selfplay_stats()))
+        e.close()
+    (a_rows, a_stats), (b_rows, b_stats) = out
+    assert a_rows.shape[0] == steps * 4096
+    np.testing.assert_array_equal(a_rows.view(np.uint32), b_rows.view(np.uint32))
+    for x, y in zip(a_stats, b_stats):
+        np.testing.assert_array_equal(x, y)
+    if which == "cartpole_4096":
+        assert a_stats[1].sum() > 0      # episodes did end (and restart) inside the window
+
+
 # ------------------------------------------------------------------------------------------------ T7: the reference's run loops
 
 T7 = sorted(os.path.basename(p)[len("t7_selfplay_"):-4] for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t7_selfplay_*.npz")))
