@@ -598,7 +598,8 @@ def _t3_scale_chunk(job):
     reference's DiagonalNormalPolicy; 'b': CartPole discrete with its DiscretePolicy)."""
     kind, hidden, n_rollouts, lo, hi, roots, seed = job
     torch.set_num_threads(1)
-    cont = kind not in ("b", "d")
+    cont = kind not in ("b", "d", "m")
+    car = kind == "m"           # gym MountainCar-v0: three actions, observation = (position, velocity)
     gmm = kind == "g"           # the reference's default continuous policy: 2-component mixture (config/policy/ContinuousPolicy.yaml)
     eps = 0.1 if kind == "d" else 0.0   # the reference's default discrete search: epsilon-greedy 0.1 (config/mcts/MCTSDiscrete.yaml)
     if gmm:
@@ -611,6 +612,11 @@ def _t3_scale_chunk(job):
         pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
                           num_components=1, action_bound=2.0)
         set_policy_weights(pol, blob, 3, hidden, 2)
+    elif car:
+        blob = O.make_weights(34, 2, hidden, 3)
+        pol = make_policy(representation_dim=2, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
+                          num_actions=3)
+        set_policy_weights(pol, blob, 2, hidden, 3)
     else:
         blob = O.make_weights(34, 4, hidden, 2)
         pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
@@ -652,6 +658,10 @@ def _t3_scale_chunk(job):
                 env = PendulumEnv(state=roots[ti - lo], version=1)
                 m = RM.MCTSContinuous(model=pol, n_rollouts=n_rollouts, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
                                       V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
+            elif car:
+                env = MountainCarEnv(state=roots[ti - lo])
+                m = RM.MCTSDiscrete(model=pol, num_actions=3, n_rollouts=n_rollouts, c_uct=0.8, gamma=0.99, epsilon=0.0,
+                                    V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
             else:
                 env = CartPoleEnv(state=roots[ti - lo])
                 m = RM.MCTSDiscrete(model=pol, num_actions=2, n_rollouts=n_rollouts, c_uct=1.5, gamma=1, epsilon=eps,
@@ -675,11 +685,13 @@ T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engi
     # trunk with 25 rollouts; 2x128 ReLU with 8 rollouts and epsilon-greedy 0.1 (draws: the engine's, injected as `random`)
     "g": (2, 1, [128, 128, 128], "elu", 25, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
     "d": (0, 0, [128, 128], "relu", 8, 1024, dict(c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1)),
+    # three actions end to end: gym MountainCar-v0 with the reference's DiscretePolicy (2x64 ReLU), 60 rollouts, gamma 0.99
+    "m": (3, 0, [64, 64], "relu", 60, 1024, dict(c_uct=0.8, gamma=0.99, num_actions=3)),
 }
 T3_SCALE_FULL = 1024   # trees per leg whose Q / actions / value target are stored as well (visit counts: every tree)
 
 
-def run_t3_scale(procs=8):
+def run_t3_scale(procs=8, only=None):
     """T3 at BASELINE scale (VERDICT r03 row g): the reference's MCTSContinuous.search / MCTSDiscrete.search (mcts.py:418-462,
     656-702) with its REAL torch policies (policies.py:340-352, 436-499) on the engine's own synthetic roots 0..N-1 of configs C
     (all 4096 trees, 2x256 ELU, 200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU,
@@ -689,11 +701,14 @@ def run_t3_scale(procs=8):
     import multiprocessing as mp
     out = {}
     for tag, (env_id, mode, hidden, act, n_roll, B, kw) in T3_SCALE.items():
+        if only and tag not in only:
+            continue
         eng = O.OracleEngine(env_id=env_id, mode=mode, n_trees=B, n_sims=n_roll, seed=34, **kw)
         roots = eng.synthetic_roots()
-        n_dist = 6 if tag == "g" else 2
-        eng.set_weights(_capi.make_desc(4 if mode == 0 else 3, hidden, n_dist, act, num_components=2 if tag == "g" else 0),
-                        O.make_weights(35 if tag == "g" else 34, 4 if mode == 0 else 3, hidden, n_dist))
+        n_dist = 6 if tag == "g" else (3 if tag == "m" else 2)
+        in_dim = 2 if tag == "m" else (4 if mode == 0 else 3)
+        eng.set_weights(_capi.make_desc(in_dim, hidden, n_dist, act, num_components=2 if tag == "g" else 0),
+                        O.make_weights(35 if tag == "g" else 34, in_dim, hidden, n_dist))
         eng.trace_enable()
         eng.search(roots)
         ro = eng.results()
@@ -736,9 +751,14 @@ def run_t3_scale(procs=8):
     return out
 
 
-def main_scale():
-    res = run_t3_scale()
+def main_scale(only=None):
+    """`scale`: every leg; `scale m g ...`: only the named legs, merged into the existing fixture."""
     path = os.path.join(HERE, "t3_scale.npz")
+    res = {}
+    if only and os.path.exists(path):
+        with np.load(path) as z:
+            res = {k: z[k] for k in z.files}
+    res.update(run_t3_scale(only=only))
     np.savez_compressed(path, **res)
     print("t3_scale.npz", os.path.getsize(path), "bytes")
 
@@ -1129,6 +1149,8 @@ def main():
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
             print(name, "records", res["n_records"].tolist(), "counts", res["counts"].tolist())
         return
+    if sys.argv[1:2] == ["scale"] and len(sys.argv) > 2:   # only the named legs of t3_scale.npz
+        return main_scale(sys.argv[2:])
     if sys.argv[1:] == ["scale"]:  # only t3_scale.npz: the reference with its torch policies on 4096 + 4096 + 128 synthetic roots
         return main_scale()
     if sys.argv[1:] == ["wide"]:   # only the wide-network T2 cases and the n_rollouts = 200 T3 legs

@@ -3,14 +3,15 @@ MCTSContinuous.search / MCTSDiscrete.search (alphazero/search/mcts.py:418-462, 6
 (alphazero/network/policies.py:340-352, 436-499) -- on the engine's own synthetic roots of configs C (all 4096 trees, 2x256 ELU,
 200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
 each -- of the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): the 2-component mixture head on a
-3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`):
+3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`);
+and 1024 trees of gym MountainCar-v0 (three actions) with the reference's DiscretePolicy:
 tests/golden/t3_scale.npz, written by tests/golden/gen_golden.py `scale` from the imported reference.
 
 The networks differ from torch's by ~1e-7 (summation order), so a selection whose two best scores are closer than that could
 legitimately flip.  The test therefore reports a MATCH RATE and attributes every mismatching tree: the fixture holds, for the trees
 whose counts differed from the oracle's when it was generated, the reference's per-trace leaf records; the test finds the first
 trace at which the oracle leaves the reference's sequence and requires the oracle's tightest arg-max gap on that trace to be below
-1e-6 (a near-tie) -- anything else is a real difference and fails.  (When this fixture was generated: 1 mismatching tree of 10368 -- config C's tree 1815 leaves the reference's sequence at trace 24,
+1e-6 (a near-tie) -- anything else is a real difference and fails.  (When this fixture was generated: 1 mismatching tree of 11392 -- config C's tree 1815 leaves the reference's sequence at trace 24,
 where the oracle's two best scores are 2.07e-8 apart.)
 """
 import os
@@ -32,10 +33,13 @@ LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims, network ou
     # the reference's own default configurations (config/mcts/*.yaml, config/policy/*.yaml): mixture head, 25 rollouts; epsilon-greedy 0.1, 8 rollouts
     "g": (dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34), 3, [128, 128, 128], "elu", 25, 6, 2, 35),
     "d": (dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1, seed=34), 4, [128, 128], "relu", 8, 2, 0, 34),
+    # three actions end to end: gym MountainCar-v0 with the reference's DiscretePolicy (2x64 ReLU), 60 rollouts, gamma 0.99
+    "m": (dict(env_id=3, mode=0, c_uct=0.8, gamma=0.99, num_actions=3, seed=34), 2, [64, 64], "relu", 60, 3, 0, 34),
 }
-N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024
+N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024 + 1024
 NAMES = {"c": "config C", "b": "config B", "e": "config E", "g": "the reference's default continuous setup (mixture head, 25 rollouts)",
-         "d": "the reference's default discrete setup (epsilon-greedy 0.1, 8 rollouts)"}
+         "d": "the reference's default discrete setup (epsilon-greedy 0.1, 8 rollouts)",
+         "m": "MountainCar-v0 (three actions, 60 rollouts)"}
 
 
 def _network(leg):
@@ -63,7 +67,7 @@ def attribute(tag, tree, ref_leaf, root):
     return d, (float(margin[0, d]) if d >= 0 else float("inf"))
 
 
-def _scale(engine_cls, legs=("c", "b", "e", "g", "d")):
+def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m")):
     z = np.load(os.path.join(P.GOLDEN, "t3_scale.npz"))
     total = matched = 0
     lines = []
