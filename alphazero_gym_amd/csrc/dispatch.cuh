@@ -59,10 +59,11 @@ static hipError_t launch_t(azg_engine* e) {
 }
 
 // Variant choice.  Trees live in LDS when they fit (8-bit record ids, 16-bit counts, <= 16 children per node, the CU's 160 KB).
-// While every 16-tree group can have a CU of its own, the 4-wave / 16-tree workgroup is the fastest shape (measured: the
-// 8-wave / 16-tree shape ties with it, the VALU work per SIMD being the same).  Once a batch has more groups than the device
-// has CUs, 2x256 Normal / 2-action networks run as 8-wave / 32-tree workgroups: two waves per SIMD, so one wave's tree walk
-// and activation math overlaps the other's MFMAs (1.27x at 8192 trees).  AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
+// The general shape is the 4-wave / 16-tree workgroup.  2x256 squashed-Normal networks (continuous mode) run with eight waves: while
+// every 16-tree group can have a CU of its own, as 16-tree workgroups whose eight waves share the network phase and whose first four
+// walk the trees (4 % faster than four waves; with all eight walking it only tied); once a batch has more groups than the device has
+// CUs, as 32-tree workgroups: one wave's tree walk and activation math overlaps the other's MFMAs (1.27x at 8192 trees).
+// AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
 template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {
     const int ns = e->cfg.n_sims;
@@ -81,8 +82,9 @@ static hipError_t launch(azg_engine* e) {
         bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
         if (e->opt.groups == 2) two = true;
         if (e->opt.groups == 1) two = false;
-        bool want8 = two;
-        if (e->opt.waves == 8) want8 = true;
+        // eight waves either way (round 4): 32-tree workgroups when the batch has more groups than CUs, else 16-tree workgroups whose
+        // eight waves share the network phase while four of them walk the trees (search_kernel.cuh).  AZG_WAVES=4 forces the old shape.
+        bool want8 = true;
         if (e->opt.waves == 4) want8 = false;
         if (want8 && ts == TS_LDS8 && e->P.ncomp < 2) {
             hipError_t rc = hipErrorInvalidConfiguration;

@@ -1,7 +1,7 @@
 // search_kernel.cuh -- the persistent search kernel: one launch = all n_sims traces of B trees.  A workgroup of NW waves
 // owns NG groups of 16 trees (one 16-column MFMA tile each):
 //   NW = 4, NG = 1: one wave per SIMD, 4 trees per wave (any network);
-//   NW = 8, NG = 1: two waves per SIMD, 2 trees per wave: half the activation math and less tree-walk divergence per wave;
+//   NW = 8, NG = 1: two waves per SIMD for the network phase, four of the eight walk the trees (4 each): the shape of BASELINE config C;
 //   NW = 8, NG = 2: two waves per SIMD, 32 trees: one wave's tree walk / activation math overlaps the other's MFMAs
 //                   (pays off when the batch has more 16-tree groups than the device has CUs).
 // NT < 16 ("half-filled tiles"): a group holds only NT = 8 (or 4) trees, the other columns of its MFMA tile carry zeros: more,
@@ -46,7 +46,13 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     static_assert(NT == 16 || (NG == 1 && NW == 4 && (NT == 8 || NT == 4)), "half-filled tiles: one group, four waves");
     constexpr int TPW = NT * NG;        // trees per workgroup
-    constexpr int TPV = TPW / NW;       // trees per wave (16 lanes each; the wave's other lanes sit the tree phases out)
+    // NW = 8, NG = 1 (one 16-tree group, eight waves): all eight waves share the network phase -- a tile fewer each, and the two
+    // waves of a SIMD cover each other's LDS round trips and barrier skew there -- but only the first four walk trees (four each,
+    // one walking wave per SIMD: waves w and w + 4 share SIMD w).  With all eight walking (two trees each) the SIMT tree phases
+    // are issued twice per SIMD and the shape only ties with the 4-wave one; with four walkers it is 4 % faster (config C on
+    // MI355X, same box: 1.649 against 1.725 ms per search; all eight walking: 1.707).
+    constexpr int NWALK = (NW == 8 && NG == 1) ? 4 : NW;
+    constexpr int TPV = TPW / NWALK;    // trees per walking wave (16 lanes each; the wave's other lanes sit the tree phases out)
     typedef typename TreeStore<TLDS>::Rec Rec;
     constexpr int NCH = head_chunks<HP>();   // partial head sums per tree
     constexpr int PSTR = GMM ? 64 : 16;      // entries kept per chunk: all 16 output rows, or rows 0..3 (value + Normal / 2 actions)
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
         Ctx c;
         const int w = t >> 6, ln = t & 63;
         c.sub = ln & 15;
-        c.has_tree = (ln >> 4) < TPV;
+        c.has_tree = w < NWALK && (ln >> 4) < TPV;
         c.tl = c.has_tree ? w * TPV + (ln >> 4) : 0;   // tree within the workgroup
         c.tree = blockIdx.x * TPW + c.tl;
         c.live = c.has_tree && c.tree < P.B;

@@ -140,14 +140,14 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
-@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "groups2",
+@pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "waves4", "groups2",
                                      "trace_cap1", "trace_cap64", "tile16"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
     instead of LDS, for wide networks (default: the persistent team kernel) the one-launch search kernel and the per-layer
-    launches, and for 2x256 networks the 8-wave workgroup shapes: 16 trees (diagnostic) and 32 trees (chosen by
-    itself only for batches of more 16-tree groups than CUs); in discrete mode one trace per simulation step (the round-3 loop)
+    launches, and for 2x256 networks the workgroup shapes: eight waves / 16 trees (four of them walking: the default in continuous
+    mode), four waves (the general shape) and eight waves / 32 trees (chosen by itself for batches of more 16-tree groups than CUs); in discrete mode one trace per simulation step (the round-3 loop)
     and as many as a tree can run without the network (default: at most four); full 16-tree tiles where small batches of small
     networks take half-filled ones."""
     env, mode, hidden, act, n_sims, extra = cfg
@@ -158,10 +158,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         monkeypatch.setenv("AZG_FORCE_STREAM_WEIGHTS", "1")
     if variant == "global_tree":
         monkeypatch.setenv("AZG_FORCE_GLOBAL_TREE", "1")
-    if variant in ("waves8", "groups2"):
+    if variant in ("waves8", "waves4", "groups2"):
         if hidden != [256, 256] or ln or ncomp or mode != 1:
             pytest.skip("the 8-wave workgroups exist for 2x256 squashed-Normal networks (continuous mode)")
-        monkeypatch.setenv(*(("AZG_WAVES", "8") if variant == "waves8" else ("AZG_GROUPS", "2")))
+        monkeypatch.setenv(*(("AZG_WAVES", variant[-1]) if variant.startswith("waves") else ("AZG_GROUPS", "2")))
     if variant in ("trace_cap1", "trace_cap64"):
         if mode != 0 or max(hidden) > 256:
             pytest.skip("several traces per step: the discrete persistent search kernels")
