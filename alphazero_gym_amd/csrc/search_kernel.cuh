@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     // is rebuilt from the thread index at the top of every tree phase, the loop-carried tree state crosses the network phase
     // packed two fields to a register, and the path's rewards / returns are fetched after the network phase instead of during
     // the descent.  With one wave per SIMD (NW = 4: 512 registers) everything stays in registers (measured faster there).
-    constexpr bool LEAN = (NW == 8);
+    constexpr bool LEAN = (NW == 8);   // (also for the 16-tree shape: carrying everything instead costs 7 spilled registers and 0.7 % time)
     const LdsLayout L = lds_layout(P.tab_n, P.n_sims, HP, NG, act_buffers(NREG), P.R, CONT, TLDS, P.lds_state, NT);
     double* s_sqrt = s_dyn;
     unsigned short* s_pw = (unsigned short*)(s_dyn + P.tab_n);   // widening thresholds, clamped (a node has < 32768 children)

@@ -565,8 +565,8 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
 
 
 def test_headline_search_stays_within_its_time_budget(native):
-    """Guard against performance regressions of the one-launch search (BASELINE config C).  Measured 1.65-1.70 ms per search on
-    MI355X boxes (4.8-4.95e8 sims/s); budget = +15 % of the slowest box seen (best of five warm launches)."""
+    """Guard against performance regressions of the one-launch search (BASELINE config C).  Measured 1.60-1.64 ms per search on
+    MI355X boxes (5.0-5.1e8 sims/s; eight waves, four walking); budget = +15 % of the slowest box seen (best of five warm launches)."""
     kw = dict(env_id=2, mode=1, n_trees=4096, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e = native.HipEngine(**kw)
     e.set_weights(_capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2))
@@ -576,7 +576,7 @@ def test_headline_search_stays_within_its_time_budget(native):
     e.sync()
     ms = min(_timed_ms(e) for _ in range(5))
     e.close()
-    assert ms < 1.95, f"search kernel took {ms:.3f} ms (budget 1.95 ms = 4.2e8 sims/s)"
+    assert ms < 1.88, f"search kernel took {ms:.3f} ms (budget 1.88 ms = 4.36e8 sims/s)"
 
 
 def _timed_ms(e):

@@ -47,6 +47,12 @@ def main():
     n = lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), len(buf))
     assert n >= rows
     buf = buf[:rows]
+    if waves == 8 and groups == 1:
+        # eight waves share the network phase, the first four walk the trees: report the walkers (the helpers wait at the barrier meanwhile)
+        walker = (np.arange(rows) % 8) < 4
+        print(f"helper waves (4 of 8 per workgroup): barrier wait {buf[~walker, 0].astype(np.float64).mean() / (n_sims + 1):.0f}, network "
+              f"{buf[~walker, 1].astype(np.float64).mean() / (n_sims + 1):.0f} cycles/step; the lines below are the WALKING waves")
+        buf = buf[walker]
     names = ["barrier wait", "network (MLP)", "finish leaf + backup", "select/step/expand"]
     tot = buf[:, :4].sum(1).mean()
     for i, nm in enumerate(names):
