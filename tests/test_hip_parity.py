@@ -363,7 +363,8 @@ def test_config_e_full_size_lockstep(native):
     roots = e.synthetic_roots()
     e.search(roots)
     r, d = e.results(), e.dump_tree()
-    ms = e.last_search_ms()
+    e.upload_roots(roots)
+    ms = min(_timed_ms(e) for _ in range(3))     # (warm launches: the first one of a process also loads the code object: up to 14.9 ms)
     e.close()
     assert (r["n_children"] == 15).all()
     _tree_invariants(r, d, NS, range(B))
