@@ -7,15 +7,19 @@
 
 N = 1  (config C): a "step" is one whole search (4096 trees x 200 simulations = ONE launch of the fused search kernel) over
        synthetic fixed-seed root states already resident in HBM, return_results of every tree included (written into device
-       buffers by the search kernel's epilogue; azg_results_resident hands them out, no copy).  The JSON line also carries `extra`: configs B and E timed
-       the same way, the PCIe-inclusive rate of config C, and the CPU baselines.
+       buffers by the search kernel's epilogue; azg_results_resident hands them out, no copy).  The JSON line also carries `roofline`
+       (fp32 MFMA; `traffic` = HBM bytes per launch from two rocprofv3 --pmc child passes of this run), `roofline_hbm` (the tree walk's
+       algorithmic bytes, counted from the searched trees, against the HBM peak), `cpu_baseline`, and `extra`: configs B and E and C at
+       8192 trees timed the same way (B with its HBM-side block, E with its hardware MFMA-busy share), `mfma_busy` (the hardware's view
+       of roofline.frac), `config_d_1rank` (the N > 1 workload on this one GPU, no collectives) and the PCIe-inclusive rate of config C.
        `--config-d` runs the N > 1 loop (below) with one rank: the collectives then go through RCCL with world size 1.
 N > 1  (config D): one process per GPU (spawned here when the script was not started by torch.distributed.run), 4096 self-play
        games per GPU keyed by global game id.  A step is one device-resident self-play step (search + final action + env step +
        replay row) PLUS the all-gather of the step's replay rows over RCCL (HBM to HBM, overlapped with the next step's search)
        and a weight broadcast + engine re-sync (device to device: azg_set_weights_device) every --bcast-every steps: the loop
        shape of run_continuous.py:111-155 scaled out.
-       `extra.search_only` is the same loop without the collectives.
+       `extra.search_only` is the same loop without the collectives; rank 0 adds `cpu_baseline` after the timed region.
+       Rendezvous and collectives are bounded (--dist-timeout): a rank that never arrives or dies fails the run instead of hanging it.
 Rank 0 prints ONE JSON line.
 """
 import argparse
