@@ -6,7 +6,7 @@ a leaf and expand) plus one cheaper round (c_more) for every further trace its b
 an evaluation or at the cap.  With the stamped build's costs (k cycles: 4.4 / 6.1 / 4.0) the model gives, per trace, 10.5k at cap 1,
 8.2k at 2, 7.7k at 3, 7.5k at 4, 7.4k at 5, 7.5k at 6, 8.5k at 8 -- the shape that was measured on the GPU (0.484 / 0.41 / 0.388 /
 0.375 / 0.371 / 0.371 / 0.43 ms).  "Catch-up" caps for trees that lag behind a target pace come out worse (8.6k+): they lengthen the
-steps of everybody.  CPU only (uses the oracle: test infrastructure):  python tools/cap_model.py"""
+steps of everybody.  CPU only (uses the oracle: test infrastructure):  python tests/cap_model.py"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak on the GPU box: the random-configuration parity test of tests/test_hip_parity.py over many more seeds
-(python tools/fuzz_parity.py [first_seed] [count]); prints the seeds that disagree with the oracle, if any."""
+(python tests/fuzz_parity.py [first_seed] [count]); prints the seeds that disagree with the oracle, if any."""
 import os
 import sys
 import time

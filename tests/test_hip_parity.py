@@ -536,10 +536,10 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     env, mode, hidden, act, ln, n_sims, extra, ncomp, in_dim, n_dist = _random_case(rng)
     B = int(rng.choice([1, 5, 16, 19, 33]))
-    if os.environ.get("AZG_FUZZ_BIG"):      # tools/fuzz_parity.py: batches of several workgroups (ragged), 32-tree workgroups
+    if os.environ.get("AZG_FUZZ_BIG"):      # tests/fuzz_parity.py: batches of several workgroups (ragged), 32-tree workgroups
         B = int(rng.choice([19, 70, 130, 257, 515]))
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=int(rng.integers(1, 1 << 30)), tree_id_base=int(rng.integers(0, 1000)), **extra)
-    if os.environ.get("AZG_FUZZ_SHAPES"):   # tools/fuzz_parity.py: also the 8-wave workgroup shapes, global trees, weights from L2
+    if os.environ.get("AZG_FUZZ_SHAPES"):   # tests/fuzz_parity.py: also the 8-wave workgroup shapes, global trees, weights from L2
         os.environ.pop("AZG_WAVES", None); os.environ.pop("AZG_GROUPS", None); os.environ.pop("AZG_FORCE_GLOBAL_TREE", None); os.environ.pop("AZG_FORCE_STREAM_WEIGHTS", None)
         os.environ.pop("AZG_TRACE_CAP", None); os.environ.pop("AZG_TILE_TREES", None)
         cap = int(rng.choice([0, 0, 1, 2, 3, 7, 1000]))

@@ -187,3 +187,16 @@ print("CREATE", rc, b"two HIP runtimes" in lib.azg_last_error(None))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "CONFLICT True" in out.stdout, out.stdout + out.stderr
     assert "CREATE -3 True" in out.stdout, out.stdout + out.stderr
+
+
+def test_only_the_checkers_touch_the_oracle():
+    """The oracle is test infrastructure: besides tests/, only bench.py (its cpu_baseline leg) and __graft_entry__.py (smoke) may
+    import or load it -- no tool, example or package module."""
+    import glob
+    offenders = []
+    for pat in ("tools/**/*.py", "tools/**/*.sh", "examples/**/*.py", "alphazero_gym_amd/**/*.py"):
+        for f in glob.glob(os.path.join(ROOT, pat), recursive=True):
+            txt = open(f).read()
+            if "oracle_lib" in txt or "libazg_oracle" in txt or "OracleEngine" in txt or "import test_hip_parity" in txt:
+                offenders.append(os.path.relpath(f, ROOT))
+    assert not offenders, offenders
