@@ -576,7 +576,11 @@ def test_headline_search_stays_within_its_time_budget(native):
         e.search_resident()
     e.sync()
     ms = min(_timed_ms(e) for _ in range(5))
+    import ctypes as C
+    buf = C.create_string_buffer(256)
+    native.lib().azg_debug_kernel_name(C.c_void_p(e._h.value), buf, C.c_size_t(256))
     e.close()
+    assert buf.value.decode() == "search_kernel<2, 256, 1, 1, false, 8, 1, 16>"    # eight waves, four of them walking
     assert ms < 1.88, f"search kernel took {ms:.3f} ms (budget 1.88 ms = 4.36e8 sims/s)"
 
 
