@@ -18,6 +18,56 @@ def test_flop_and_core_counts():
     assert 1 <= bench.physical_cores() <= (os.cpu_count() or 1)
 
 
+def test_no_profiler_child_passes_under_a_profiler(monkeypatch):
+    """bench.py's live PMC passes start rocprofv3 children; when bench.py itself already runs under rocprofv3 the
+    tool library is preloaded into every child, and a nested rocprofv3 would re-exec a process whose GPU runtime is initialised.
+    live_traffic() must refuse there, and the children's environment must carry nothing a profiler left behind."""
+    import bench
+    for var, val in (("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("ROCPROF_COUNTER_COLLECTION", "1"),
+                     ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")):
+        monkeypatch.setenv(var, val)
+        assert bench.under_profiler()
+        assert bench.live_traffic(16) == (None, "already under a profiler")
+        env = bench.clean_child_env()
+        assert "LD_PRELOAD" not in env and not [k for k in env if k.startswith("ROCP")] and env["TMPDIR"] == "/tmp"
+        monkeypatch.delenv(var)
+    assert not bench.under_profiler()
+
+
+def test_walk_bytes_of_a_widening_search_are_counted_from_the_trees():
+    """roofline_hbm of the headline line: L / C / E of SURVEY 8d's byte formula reconstructed from a searched batch (oracle double):
+    the children scored are a function of every node's visit count under the widening law; the reconstruction must land on the
+    survey's probe values (L 2.64, C 11.45, E 1.0 for 200 rollouts) and on an exact recount for a small case."""
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from alphazero_gym_amd import _capi
+    e = O.OracleEngine(n_trees=64, n_sims=200, **bench.PENDULUM)
+    e.set_weights(_capi.make_desc(3, bench.HIDDEN, 2, "elu"), O.make_weights(34, 3, bench.HIDDEN, 2))
+    e.search(e.synthetic_roots())
+    per_sim, L, C, E = bench.tree_walk_bytes_continuous(e.dump_tree(), 200, 1.0, 0.5)
+    e.close()
+    assert E == 1.0 and 2.3 < L < 3.0 and 10.0 < C < 13.0 and 400 < per_sim < 520
+    # every node's final child count must equal what the reconstruction's law gives for its visit count (the same walk the formula takes)
+    d = None
+    e = O.OracleEngine(n_trees=4, n_sims=60, **bench.PENDULUM)
+    e.set_weights(_capi.make_desc(3, bench.HIDDEN, 2, "elu"), O.make_weights(34, 3, bench.HIDDEN, 2))
+    e.search(e.synthetic_roots())
+    d = e.dump_tree()
+    e.close()
+    import math
+    for t in range(4):
+        n = int(d["n_records"][t])
+        kids = np.bincount(d["parent"][t][1:n], minlength=n)
+        for j in range(n):
+            K = 1 if j == 0 else 0
+            for v in range(int(d["node_n"][t][j])):
+                if math.ceil((v + 1) ** 0.5) > K:
+                    K += 1
+            assert K == kids[j], (t, j, K, kids[j])
+
+
 def test_gpus_must_match_world_size():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True)
