@@ -654,7 +654,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname + " (template arguments: ENV 2 = Pendulum, HP = padded hidden width, NREG = hidden->hidden layers held in "
-                                   "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup, 16-tree groups per workgroup)",
+                                   "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup -- eight, of which the first four walk the trees --, "
+                                   "tree groups per workgroup, trees per group)",
                          "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "
