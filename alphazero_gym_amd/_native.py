@@ -47,7 +47,7 @@ def _check_load_order():
     if spec is None or not spec.origin:
         return
     bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(bundled) and os.path.realpath(bundled) not in have:
+    if os.path.exists(bundled) and os.path.realpath(bundled) not in have and os.environ.get("AZG_ALLOW_MULTI_HIP") != "1":
         raise HipRuntimeConflict(
             f"a HIP runtime is already mapped in this process ({', '.join(sorted(have))}) and PyTorch, which has not been imported yet, "
             f"bundles another one ({bundled}): with both loaded torch.cuda finds no GPU or hangs. Import torch before anything loads "
@@ -75,9 +75,16 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         both = mapped_hip_runtimes()
         if len(both) > 1:
-            _lib = None
-            raise HipRuntimeConflict(f"two HIP runtimes are mapped in this process ({', '.join(sorted(both))}): import torch before anything "
-                                     "else loads a HIP library (INTEGRATION.md section 1)")
+            msg = (f"two HIP runtimes are mapped in this process ({', '.join(sorted(both))}). If torch was NOT imported first: import torch "
+                   "before anything else loads a HIP library (INTEGRATION.md section 1). If it was (the wheel's libamdhip64 and the system's "
+                   "differ in SONAME, or some other library maps a second copy on purpose) and both work side by side in your process: "
+                   "set AZG_ALLOW_MULTI_HIP=1 to turn this error into a warning.")
+            if os.environ.get("AZG_ALLOW_MULTI_HIP") == "1":
+                import warnings
+                warnings.warn(msg, RuntimeWarning)
+            else:
+                _lib = None
+                raise HipRuntimeConflict(msg)
         _fns = _capi.bind(_lib, "azg_")
         ver = _fns["abi_version"]()
         if ver != _capi.ABI_VERSION:

@@ -98,6 +98,17 @@ static int ls_prepare(azg_engine* e) {
     return AZG_OK;
 }
 
+// Rows (16 counters each) of the diagnostic stamp buffer: one per wave of the search kernel -- four waves per 4 trees at the least
+// filled tile shape, eight waves per 16-tree workgroup (also when the batch has fewer than 16 trees) -- or eight counters per
+// team-kernel workgroup (16 workgroups per 32 trees, at least one team).
+static size_t stamp_rows(size_t B) {
+    size_t r = ((B + 3) / 4) * 4;
+    const size_t r8 = ((B + 15) / 16) * 8, team = ((B + 31) / 32) * 16 / 2;
+    if (r8 > r) r = r8;
+    if (team > r) r = team;
+    return r < 16 ? 16 : r;
+}
+
 static int env_digit(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && v[0] >= '0' && v[0] <= '9') ? v[0] - '0' : dflt;
@@ -162,6 +173,11 @@ void azg_engine_destroy(azg_engine* e) {
 // the second one to initialise then finds no GPU or hangs.  Seen from here as two different libamdhip64 files in the process's
 // memory map; reported instead of risking either.  Returns the number of distinct files and their paths.
 static int mapped_hip_runtimes(std::string& paths) {
+    // scanned once per process: the answer can only change by loading yet another runtime behind this library's back, and a process
+    // that creates engines in a loop should not re-parse its memory map every time
+    static int cached_n = -1;
+    static std::string cached_paths;
+    if (cached_n >= 0) { paths = cached_paths; return cached_n; }
     std::vector<std::string> seen;
     FILE* f = fopen("/proc/self/maps", "r");
     if (!f) return 0;
@@ -179,16 +195,20 @@ static int mapped_hip_runtimes(std::string& paths) {
     fclose(f);
     paths.clear();
     for (const auto& q : seen) paths += (paths.empty() ? "" : ", ") + q;
-    return (int)seen.size();
+    cached_paths = paths;
+    cached_n = (int)seen.size();
+    return cached_n;
 }
 
 int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(nullptr, AZG_E_INVALID, "null argument");
     {
         std::string rts;
-        if (mapped_hip_runtimes(rts) > 1)
+        const char* allow = getenv("AZG_ALLOW_MULTI_HIP");
+        if (mapped_hip_runtimes(rts) > 1 && !(allow && allow[0] == '1'))
             return fail(nullptr, AZG_E_DEVICE, ("two HIP runtimes are mapped in this process (" + rts + "): load PyTorch (import torch) BEFORE "
-                                               "libazgym_hip.so so that both use PyTorch's copy").c_str());
+                                               "libazgym_hip.so so that both use PyTorch's copy; if they are meant to coexist (differing "
+                                               "SONAMEs, a deliberate second copy), set AZG_ALLOW_MULTI_HIP=1").c_str());
     }
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
@@ -303,7 +323,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     CK(dalloc(e, &e->d_rootdist, B * e->nd, e->dev_allocs));
     {
         unsigned long long* st;
-        CK(dalloc(e, &st, ((B + 3) / 4) * 4 * 16, e->dev_allocs));   // (diagnostic builds: one row per wave; at most 4 waves per 4 trees)
+        CK(dalloc(e, &st, stamp_rows(B) * 16, e->dev_allocs));   // (diagnostic builds: one row of 16 counters per wave)
         e->P.stamps = st;
     }
     std::vector<double> sq(e->tab_n);
@@ -833,7 +853,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows
 int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows) {
     if (!e || !out) return AZG_E_INVALID;
-    size_t rows = (size_t)((e->cfg.n_trees + 3) / 4) * 4;
+    size_t rows = stamp_rows((size_t)e->cfg.n_trees);
     if (rows > max_rows) rows = max_rows;
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));

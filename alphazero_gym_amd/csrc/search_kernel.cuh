@@ -158,6 +158,8 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     // leaves when all of its trees are done (s_done, read by everyone right after the step's first barrier).
     // Continuous mode (every trace widens a node and evaluates the new leaf): one trace per step, as before.
     constexpr bool MULTI = !CONT;
+    // (the lean packing below does not carry TreeState::chainR / repeat nor the MULTI loop's per-tree trace counter)
+    static_assert(!(LEAN && MULTI), "discrete 8-wave shapes: extend the LEAN packing first");
     int my_sim = -1;                    // the trace whose leaf is pending (-1: the root's evaluation); n_sims: the tree is done
     const int n_live = (P.B - (int)blockIdx.x * TPW) < TPW ? (P.B - (int)blockIdx.x * TPW) : TPW;
     // (every unfinished tree completes at least one trace per step, so n_sims + 1 steps always suffice: the bound is a guard, the
@@ -234,11 +236,6 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
                     __threadfence_block();
                     k += 1;
                     if (st.need_eval || k >= P.trace_cap) run = false;
-                    else if constexpr (LEAN) {
-                        // (the lean descent leaves the path's rewards / returns to be fetched before the backup)
-                        st.pr = 0.0; st.pW = 0.0;
-                        if (st.my_depth >= 1) { st.pr = discrete_env_reward(P.env_id); st.pW = cx.edge_W[st.pid]; }
-                    }
                 }
                 STAMP(t_e);
                 STAMP_ADD(2, t_c2, t_d);   // finish leaf + backup

@@ -35,19 +35,37 @@ def unpack_replay_rows(rows: torch.Tensor, state_dim: int, K: int):
     return s, a, c, q, r[:, -1]
 
 
-def gather_replay_rows(rows: torch.Tensor, device=None) -> torch.Tensor:
-    """All-gather the per-rank row blocks into [B_total, row] ordered by rank (= by global tree id).  The blocks may differ in
-    length (shard_range: by at most one row when B_total is not a multiple of the world size): the lengths are gathered first,
-    shorter blocks are padded to the longest for the collective and the padding is dropped again."""
+def gather_replay_rows(rows: torch.Tensor, device=None, counts=None, total: int = None) -> torch.Tensor:
+    """All-gather the per-rank row blocks into [B_total, row] ordered by rank (= by global tree id).
+
+    The block lengths are known without asking anybody when the rows are one per game of a `shard_range` partition: pass
+    `total` (games of the whole job; rows per game are inferred from this rank's block) or `counts` (rows of every rank).
+    Equal blocks -- config D, the common case -- then cost ONE collective into one tensor, no padding, no host sync.  Only when
+    neither is given are the lengths exchanged first (one small all-gather + a host read per rank).  Blocks that differ in length
+    (by at most one game when `total` is not a multiple of the world size) are padded to the longest for the collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
     rows = (rows.to(device) if device is not None else rows).contiguous()
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if counts is None and total is not None:
+        lo, hi = shard_range(total, dist.get_rank(), world)
+        per_game, rem = divmod(rows.shape[0], max(hi - lo, 1))
+        if hi - lo == 0 or rem:
+            raise ValueError(f"rank {dist.get_rank()} holds {rows.shape[0]} rows for {hi - lo} games of {total}")
+        counts = [(b - a) * per_game for a, b in (shard_range(total, r, world) for r in range(world))]
+    if counts is None:
+        n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n)
+        counts = [int(c.item()) for c in got]
+    counts = [int(c) for c in counts]
+    if len(counts) != world or counts[dist.get_rank()] != rows.shape[0]:
+        raise ValueError(f"counts {counts} do not describe this rank's {rows.shape[0]} rows")
     longest = max(counts)
+    if min(counts) == longest:
+        out = rows.new_empty((world * longest,) + tuple(rows.shape[1:]))
+        dist.all_gather_into_tensor(out, rows)
+        return out
     if rows.shape[0] < longest:
         rows = torch.cat([rows, rows.new_zeros((longest - rows.shape[0],) + tuple(rows.shape[1:]))], dim=0)
     out = [torch.empty_like(rows) for _ in range(world)]

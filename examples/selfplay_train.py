@@ -83,7 +83,7 @@ def train(a, log=print):
     for it in range(a.iters):
         rows = sp.collect_device(a.steps_per_iter, replay) if on_gpu else sp.collect(a.steps_per_iter)
         if world > 1:
-            rows = D.gather_replay_rows(rows)   # every rank's games
+            rows = D.gather_replay_rows(rows, total=a.games)   # every rank's games (block lengths from shard_range: no length exchange)
         info = {"loss": 0.0}
         pick = rng.choice(rows.shape[0], size=min(a.train_rows, rows.shape[0]), replace=False)
         if rank == 0:

@@ -15,7 +15,10 @@ if ROOT not in sys.path:
 
 from alphazero_gym_amd import _capi  # noqa: E402
 
-LIB_PATH = os.path.join(ROOT, "oracle", "libazg_oracle.so")
+# AZG_ORACLE_ASAN=1: the AddressSanitizer + UBSan build of the oracle (make -C oracle asan); the interpreter must then run with
+# libasan / libubsan preloaded (make -C oracle asan-test sets that up).  CPU side only.
+ASAN = os.environ.get("AZG_ORACLE_ASAN") == "1"
+LIB_PATH = os.path.join(ROOT, "oracle", "libazg_oracle_asan.so" if ASAN else "libazg_oracle.so")
 
 
 def build(force=False):
@@ -25,7 +28,7 @@ def build(force=False):
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
     )
     if force or stale:
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "-s", "asan" if ASAN else "all"])
     return LIB_PATH
 
 

@@ -37,7 +37,9 @@ def _worker(rank, world, port, q):
     lo, hi = D.shard_range(B_TOTAL, rank, world)
     roots, r = _search(hi - lo, lo)
     rows = D.pack_replay_rows(roots, r["actions"], r["counts"], r["Q"], r["v_target"])
-    allrows = D.gather_replay_rows(rows)
+    # block lengths: computed locally from shard_range (world 2: equal shards -> one all_gather_into_tensor; world 4: uneven),
+    # or exchanged first when the caller does not know the partition (world 8)
+    allrows = D.gather_replay_rows(rows, total=B_TOTAL) if world < 8 else D.gather_replay_rows(rows)
     model = torch.nn.Linear(4, 3)
     with torch.no_grad():
         for p in model.parameters():

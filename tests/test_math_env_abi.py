@@ -200,3 +200,19 @@ def test_only_the_checkers_touch_the_oracle():
             if "oracle_lib" in txt or "libazg_oracle" in txt or "OracleEngine" in txt or "import test_hip_parity" in txt:
                 offenders.append(os.path.relpath(f, ROOT))
     assert not offenders, offenders
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers():
+    """the C oracle built with -fsanitize=address,undefined (make -C oracle asan) runs oracle-backed tests clean.  Here a
+    quick subset in a child interpreter with the sanitizer runtimes preloaded (the whole set: make -C oracle asan-test, ~30 s)."""
+    import subprocess
+    import sys
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    pre = ":".join(subprocess.check_output(["gcc", f"-print-file-name={n}"], text=True).strip() for n in ("libasan.so", "libubsan.so"))
+    env = dict(os.environ, AZG_ORACLE_ASAN="1", LD_PRELOAD=pre, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_abi_errors.py"), os.path.join(ROOT, "tests", "test_properties.py")],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "passed" in out.stdout and "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
