@@ -82,19 +82,25 @@ __global__ __launch_bounds__(16 * SP_TREES) void selfplay_kernel16(KParams P, Se
     const int sub = threadIdx.x & 15;
     const int tree = blockIdx.x * SP_TREES + (threadIdx.x >> 4);
     if (tree >= P.B) return;
-    const size_t tb = (size_t)tree * P.R;
-    const RecL* hot = P.hot + tb;
     const bool cont = P.mode == AZG_MODE_CONTINUOUS;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
     const int S = P.S, K = Kmax, RL = S_obs + 3 * Kmax + 1;
     float* row = sp.rows + (size_t)tree * RL;
-    const RecL r0 = hot[0];
-    const int nc = r0.n_child;
+    // The root's children as MCTS.return_results left them (written by the search kernel's epilogue from its LDS-resident trees, or
+    // by results_kernel after the lock-step / team kernels): no tree record is read here, so a search need not publish its trees.
+    const int nc = P.res_nch[tree];
     // lane a: root child a
     const bool has = sub < nc;
-    const int kid = has ? (cont ? (int)P.child[tb * P.Kp + sub] : (int)r0.first + sub) : 0;
-    const RecL h = hot[kid];
-    const float act = has ? (cont ? P.action[tb + kid] : (float)sub) : 0.0f;
+    struct { int edge_n, node_n, flags; double Q; } h;
+    {
+        const size_t o = (size_t)tree * Kmax + (sub < Kmax ? sub : 0);
+        const int cn = P.res_child_n[o];                   // the child node's visit count, -1: the edge has no child node yet
+        h.edge_n = has ? P.res_counts[o] : 0;
+        h.Q = has ? P.res_Q[o] : 0.0;
+        h.node_n = (has && cn >= 0) ? cn : 0;
+        h.flags = (has && cn >= 0) ? FLAG_EXPANDED : 0;
+    }
+    const float act = has ? (cont ? P.res_actions[(size_t)tree * Kmax + sub] : (float)sub) : 0.0f;
     if (sub < K) {
         row[S_obs + sub] = act;
         row[S_obs + K + sub] = has ? (float)h.edge_n : 0.0f;
@@ -180,12 +186,14 @@ __global__ __launch_bounds__(16 * SP_TREES) void selfplay_kernel16(KParams P, Se
     float obs[4];
     double sn;
     // (the discrete family's observation is its state as float32: MountainCar's unused slots 2..3 are zero)
-    if (!cont) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    // (the MountainCars' observation is (position, velocity): the discrete family's state as float32 with S_obs = 2)
+    if (!cont || env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
     for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
     row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
     double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
     int done;
     if (!cont) discrete_env_step(env_id, root, pick, ns, &r, &done);
+    else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(root, pact, ns, &r, &done);
     else pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, sn, pact, ns, &r, &done);
     double ret = sp.ret[tree] + r;
     int t = sp.t[tree] + 1;
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
     float obs[4];
     double sn;
     // (the discrete family's observation is its state as float32: MountainCar's unused slots 2..3 are zero)
-    if (!cont) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    if (!cont || env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
     for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
     double qmax = 0.0, onp = 0.0;
     long tot = 0;
@@ -301,6 +309,8 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
     int done;
     if (!cont) {
         discrete_env_step(env_id, root, pick, ns, &r, &done);
+    } else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) {
+        mountaincar_cont_step(root, rv.act(pick), ns, &r, &done);
     } else {
         double s1, c1;
         azg_sincos(root[0], &s1, &c1);

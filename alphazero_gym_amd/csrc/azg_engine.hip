@@ -249,6 +249,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->d_wblob = nullptr; e->d_wmap = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
     e->d_eval = nullptr; e->eval_floats = 0;
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
+    e->publish_always = env_digit("AZG_PUBLISH_TREES", 0) == 1; e->publish_once = 0; e->published = 0; e->redo_ok = 0;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
     e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : (cfg->env_id == AZG_ENV_MOUNTAINCAR ? 2 : 3);
@@ -507,6 +508,7 @@ static int set_weights_impl(azg_engine* e, const azg_mlp_desc* d, const float* b
     // nothing below may leave a half-updated weight set usable: the flag goes up again only on success
     e->mlp_ready = 0;
     e->results_valid = 0;
+    e->redo_ok = 0;
     WeightMap& m = e->wmap;
     if (!m.valid || m.HP != HP || !same_desc(m.desc, *d)) {
         m.valid = false;
@@ -622,6 +624,7 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
         if (trc) return trc;
     }
     e->carry_max = cmax;
+    e->redo_ok = 0;
     HIPCHK(e, hipMemcpyAsync(e->d_roots, roots, sizeof(double) * (size_t)B * S, hipMemcpyHostToDevice, e->stream));
     if (carry) HIPCHK(e, hipMemcpyAsync(e->d_carry, carry, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, e->stream));
     else HIPCHK(e, hipMemsetAsync(e->d_carry, 0, sizeof(int) * (size_t)B, e->stream));
@@ -634,6 +637,7 @@ int azg_search_resident(azg_engine* e) {
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
     ON_DEVICE(e);
     e->P.search_idx = e->search_idx;
+    e->P.publish = (e->publish_always || e->publish_once) ? 1 : 0;
     e->team_search_idx = e->search_idx;
     const bool lockstep = use_lockstep(e);
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
@@ -648,6 +652,8 @@ int azg_search_resident(azg_engine* e) {
     e->search_idx += 1;
     e->searched = 1;
     e->results_valid = e->kernel_form == 0 ? 1 : 0;   // the one-launch search kernel writes return_results in its epilogue
+    e->published = (e->kernel_form != 0 || e->tree_lds == TS_GLOBAL || e->P.publish) ? 1 : 0;
+    e->redo_ok = 1;
     return AZG_OK;
 }
 
@@ -793,6 +799,20 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     ON_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     { int trc = team_check(e); if (trc) return trc; }
+    if (!e->published) {
+        // The search kernel keeps its trees in LDS and, on the product path, writes out only return_results.  A dump re-runs the
+        // last search -- same roots, weights and search index: the same trees, bit for bit -- with the trees published this once.
+        if (!e->redo_ok)
+            return fail(e, AZG_E_STATE, "the last search's trees were not written out and its inputs have changed since (self-play step, new "
+                                        "roots or weights): dump right after the search, or set AZG_PUBLISH_TREES=1");
+        e->publish_once = 1;
+        e->search_idx -= 1;
+        int rc = azg_search_resident(e);
+        e->publish_once = 0;
+        if (rc) return rc;
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        { int trc = team_check(e); if (trc) return trc; }
+    }
     size_t B = e->cfg.n_trees, R = e->R;
     std::vector<RecL> hot(B * R);
     std::vector<Cold> cold(B * R);
@@ -957,6 +977,11 @@ int azg_selfplay_step(azg_engine* e) {
     sp.rows = e->d_sp_rows + (size_t)slot * e->cfg.n_trees * e->sp_row;
     sp.roots = e->d_roots; sp.carry = e->d_carry;
     const int B = e->cfg.n_trees;
+    e->redo_ok = 0;   // (the step moves the roots on: the search that just ran cannot be re-run for a dump)
+    if (e->Kmax <= 16) {
+        rc = launch_results(e);   // return_results of this search (a launch only after the lock-step / team kernels)
+        if (rc) return rc;
+    }
     if (e->Kmax <= 16)
         hipLaunchKernelGGL(selfplay_kernel16, dim3((B + SP_TREES - 1) / SP_TREES), dim3(16 * SP_TREES), 0, e->stream, e->P, sp, e->Kmax, e->cfg.v_target, e->cfg.env_id, e->S_obs);
     else

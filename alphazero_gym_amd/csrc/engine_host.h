@@ -90,6 +90,10 @@ struct azg_engine {
     int ls_hp;
     float* d_eval; size_t eval_floats;   // scratch of azg_mlp_eval (grow-only)
     int searched, results_valid;
+    int publish_always;      // AZG_PUBLISH_TREES=1: every search writes its LDS trees out in the global format (diagnostic tools)
+    int publish_once;        // set by azg_dump_tree around its re-run of the last search
+    int published;           // the last search's trees are in global memory (global-tree / lock-step / team forms always are)
+    int redo_ok;             // roots, carried counts and weights are still the ones the last search ran on: azg_dump_tree may re-run it
     float last_ms;
     std::string err;
 };

@@ -4,11 +4,26 @@
 
 // ------------------------------------------------------------------------------------------------ environments
 
+// The kernels are instantiated per env FAMILY (template parameter ENV):
+//   AZG_ENV_CARTPOLE          discrete actions (CartPole, MountainCar-v0: the step is chosen at run time by KParams::env_id)
+//   AZG_ENV_PENDULUM_V1       one continuous action, never terminal (both Pendulum versions: KParams::v1)
+//   AZG_ENV_MOUNTAINCAR_CONT  one continuous action, episodes END (MountainCarContinuous-v0): the continuous descent has a terminal
+//                             exit and a trace may end in an existing terminal node (mcts.py:619-623, 682) -- compiled into this
+//                             family only, so that the Pendulum kernels carry no exit mask
+template <int ENV> struct EnvFamily {
+    static constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;            // MCTSContinuous (progressive widening) vs MCTSDiscrete
+    static constexpr bool TERM = ENV != AZG_ENV_PENDULUM_V1;         // nodes can be terminal
+    static constexpr int S = ENV == AZG_ENV_CARTPOLE ? 4 : 2;        // env state slots the kernels carry
+};
+
 // observation of a state; Pendulum also returns sin(theta) so that the node can cache it for its children's dynamics
 template <int ENV>
 __device__ __forceinline__ void env_obs(const double* s, float* obs, double* sn_out) {
     if (ENV == AZG_ENV_CARTPOLE) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = (float)s[2]; obs[3] = (float)s[3];
+        *sn_out = 0.0;
+    } else if (ENV == AZG_ENV_MOUNTAINCAR_CONT) {
+        obs[0] = (float)s[0]; obs[1] = (float)s[1]; obs[2] = 0.0f; obs[3] = 0.0f;   // (position, velocity)
         *sn_out = 0.0;
     } else {
         double sn, cs;
@@ -56,6 +71,29 @@ __device__ __forceinline__ void mountaincar_step(const double* s, int action, do
     o[0] = position; o[1] = velocity; o[2] = 0.0; o[3] = 0.0;
     *done = (position >= goal_position) && (velocity >= goal_velocity);
     *reward = -1.0;
+}
+
+// gym Continuous_MountainCarEnv.step (MountainCarContinuous-v0); same operation order as oracle/azg_oracle.c mountaincar_cont_step
+// and alphazero_gym_amd/envs.py MountainCarContinuousEnv.step.  The force is the action clipped to [-1, 1]; the reward's action cost
+// uses the action as it came (gym: math.pow(action[0], 2) * 0.1); +100 on reaching the flag.
+__device__ __forceinline__ void mountaincar_cont_step(const double* s, float action, double* o, double* reward, int* done) {
+    const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.45, goal_velocity = 0.0, power = 0.0015;
+    double position = s[0], velocity = s[1];
+    const double a = (double)action;
+    const double force = a < -1.0 ? -1.0 : (a > 1.0 ? 1.0 : a);
+    double sn, cs;
+    azg_sincos(3.0 * position, &sn, &cs);
+    velocity = velocity + (force * power - 0.0025 * cs);
+    velocity = velocity > max_speed ? max_speed : velocity;
+    velocity = velocity < -max_speed ? -max_speed : velocity;
+    position = position + velocity;
+    position = position > max_position ? max_position : position;
+    position = position < min_position ? min_position : position;
+    if (position == min_position && velocity < 0.0) velocity = 0.0;
+    const int d = (position >= goal_position) && (velocity >= goal_velocity);
+    o[0] = position; o[1] = velocity;
+    *done = d;
+    *reward = (d ? 100.0 : 0.0) - (a * a) * 0.1;
 }
 
 // one step of the discrete family's environment (the kernels are instantiated once per family: ENV = AZG_ENV_CARTPOLE)

@@ -113,6 +113,8 @@ struct KParams {
     int env_id;                 // AZG_ENV_* (the discrete family's kernels serve CartPole and MountainCar: env step chosen at run time)
     int trace_cap;              // discrete mode: traces a tree may run per simulation step (search_kernel.cuh; >= 1)
     int lds_state;              // discrete LDS trees: the env states of expanded nodes live in LDS too (set by the launch planning)
+    int publish;                // LDS trees: write them out in the global RecL format after the last trace (azg_dump_tree asks for it;
+                                // the product path's results come from the search kernel's epilogue and need no published tree)
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase
 };
 

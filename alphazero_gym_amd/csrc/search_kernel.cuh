@@ -258,18 +258,21 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     if (live) {
         if (sub == 0) P.n_rec[tree] = nrec;
         if constexpr (TLDS != TS_GLOBAL) {
-            // publish the LDS-resident tree in the global format
-            RecL* gh = P.hot + tb;
-            for (int j = sub; j < nrec; j += 16) {
-                Rec h = ts.hot[j];
-                RecL o;
-                o.Q = h.Q; o.edge_n = h.edge_n; o.node_n = h.node_n; o.parent = (short)h.parent; o.n_child = h.n_child;
-                o.first = CONT ? 0 : h.first; o.flags = h.flags; o.pad = 0;
-                gh[j] = o;
-                if (CONT) {
-                    for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = (unsigned short)ts.child_at(j, h, i, P.Kp);
-                } else {
-                    P.prior[tb + j] = ts.prior[j];
+            // publish the LDS-resident tree in the global format -- only when a dump asked for it (azg_dump_tree): nothing on the
+            // product path reads it, return_results was written above straight from LDS
+            if (P.publish) {
+                RecL* gh = P.hot + tb;
+                for (int j = sub; j < nrec; j += 16) {
+                    Rec h = ts.hot[j];
+                    RecL o;
+                    o.Q = h.Q; o.edge_n = h.edge_n; o.node_n = h.node_n; o.parent = (short)h.parent; o.n_child = h.n_child;
+                    o.first = CONT ? 0 : h.first; o.flags = h.flags; o.pad = 0;
+                    gh[j] = o;
+                    if (CONT) {
+                        for (int i = 0; i < (int)h.n_child; ++i) P.child[(tb + j) * P.Kp + i] = (unsigned short)ts.child_at(j, h, i, P.Kp);
+                    } else {
+                        P.prior[tb + j] = ts.prior[j];
+                    }
                 }
             }
         }

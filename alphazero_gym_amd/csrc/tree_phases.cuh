@@ -438,7 +438,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             if (CONT && FETCH) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
             if (!CONT && FETCH) { st.pr = r_step; st.pW = edge_W[chosen]; }   // (consumed by the backup; requested as the record enters the path)
         }
-        if (!CONT) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in continuous mode)
+        if constexpr (EnvFamily<ENV>::TERM) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in its kernels)
+            // `while not node.terminal` (mcts.py:441, 682): the trace ends in this existing terminal node, V = 0, no evaluation
             if (hc.flags & FLAG_TERMINAL) { hit_terminal = true; break; }
         }
         // the node's env state for the step that follows if the trace leaves the tree here: requested at every level, the wave
@@ -492,8 +493,9 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         int done;
         if (CONT) {
             if (!widen) cact = action[chosen];
-            pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
-            r = r / P.reward_scale;   // mcts.py:687
+            if constexpr (ENV == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(cp.s, cact, ns, &r, &done);
+            else pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
+            r = r / P.reward_scale;   // mcts.py:687 (whatever the env: the reference divides every continuous reward by PENDULUM_R_SCALE)
         } else {
             if constexpr (TLDS != TS_GLOBAL) {
                 if (ts.state) {

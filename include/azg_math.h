@@ -241,7 +241,8 @@ AZG_HD float azg_u01(uint32_t x) {
 #define AZG_RESET_PENDULUM 0
 #define AZG_RESET_CARTPOLE 1
 #define AZG_RESET_MOUNTAINCAR 2
-AZG_HD int azg_reset_kind(int env_id) { return env_id == 0 ? AZG_RESET_CARTPOLE : (env_id == 3 ? AZG_RESET_MOUNTAINCAR : AZG_RESET_PENDULUM); }
+/* (both MountainCar envs start at position U(-0.6, -0.4) with velocity 0) */
+AZG_HD int azg_reset_kind(int env_id) { return env_id == 0 ? AZG_RESET_CARTPOLE : ((env_id == 3 || env_id == 4) ? AZG_RESET_MOUNTAINCAR : AZG_RESET_PENDULUM); }
 AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int kind, double* s);
 
 /* the engine's draw #`draw` of stream `stream` for (global tree id, search index) */

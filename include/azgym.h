@@ -30,7 +30,9 @@ extern "C" {
 enum { AZG_OK = 0, AZG_E_INVALID = -1, AZG_E_TERMINAL_ROOT = -2, AZG_E_DEVICE = -3, AZG_E_STATE = -4, AZG_E_UNSUPPORTED = -5 };
 
 /* closed-form environments (gym classic control; call sites alphazero/search/mcts.py:443-449, 680-687) */
-enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2, AZG_ENV_MOUNTAINCAR = 3 };
+enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2, AZG_ENV_MOUNTAINCAR = 3,
+       AZG_ENV_MOUNTAINCAR_CONT = 4 /* gym MountainCarContinuous-v0: one continuous action, TERMINATES at the flag -- the
+                                       continuous search's terminal-node surface (mcts.py:599-600, 619-623, 682) */ };
 /* MCTSDiscrete (mcts.py:310-526) / MCTSContinuous (mcts.py:529-741) */
 enum { AZG_MODE_DISCRETE = 0, AZG_MODE_CONTINUOUS = 1 };
 /* V_target_policy (mcts.py:299-304) */
@@ -108,7 +110,8 @@ int azg_set_weights_device(azg_engine* e, const azg_mlp_desc* desc, const float*
 int azg_set_search_index(azg_engine* e, uint32_t idx);
 
 /* MCTS*.search(Env) (mcts.py:418-462, 656-702) for B trees.
- *   root_env_state [B][S_env] float64: CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot)
+ *   root_env_state [B][S_env] float64: CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot); both MountainCars
+ *                  (position, velocity)
  *   root_n_carry   [B] or NULL: visit count carried by a reused root (MCTSDiscrete.forward, mcts.py:495-526)
  * Terminal roots -> AZG_E_TERMINAL_ROOT (ValueError at mcts.py:382-383, 599-600). */
 int azg_search(azg_engine* e, const double* root_env_state, const int32_t* root_n_carry);
