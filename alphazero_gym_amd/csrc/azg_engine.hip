@@ -212,12 +212,12 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     }
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > 3) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
+    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_MOUNTAINCAR_CONT) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
     const bool discrete_env = cfg->env_id == AZG_ENV_CARTPOLE || cfg->env_id == AZG_ENV_MOUNTAINCAR;
     if (cfg->mode == AZG_MODE_DISCRETE && !discrete_env)
         return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole, MountainCar)");
     if (cfg->mode == AZG_MODE_CONTINUOUS && discrete_env)
-        return fail(nullptr, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
+        return fail(nullptr, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum, MountainCarContinuous)");
     if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != (cfg->env_id == AZG_ENV_CARTPOLE ? 2 : 3))
         return fail(nullptr, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3)");
     if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(nullptr, AZG_E_INVALID, "unknown tie_break");
@@ -252,7 +252,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->publish_always = env_digit("AZG_PUBLISH_TREES", 0) == 1; e->publish_once = 0; e->published = 0; e->redo_ok = 0;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
     e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
-    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : (cfg->env_id == AZG_ENV_MOUNTAINCAR ? 2 : 3);
+    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : ((cfg->env_id == AZG_ENV_MOUNTAINCAR || cfg->env_id == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3);
     const int ns = cfg->n_sims;
     std::vector<int> pw(ns + 2, 0);
     if (cfg->mode == AZG_MODE_CONTINUOUS) {
@@ -605,10 +605,12 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
             if ((s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr))
                 return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         }
-    } else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) {
+    } else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR || e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) {
+        // (mcts.py:382-383, 599-600; the flag is at 0.5 in MountainCar-v0, at 0.45 in MountainCarContinuous-v0)
+        const double goal = e->cfg.env_id == AZG_ENV_MOUNTAINCAR ? 0.5 : 0.45;
         for (int i = 0; i < B; ++i) {
             const double* s = roots + (size_t)i * S;
-            if (s[0] >= 0.5 && s[1] >= 0.0) return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
+            if (s[0] >= goal && s[1] >= 0.0) return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         }
     }
     int cmax = 0;
@@ -644,8 +646,10 @@ int azg_search_resident(azg_engine* e) {
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     hipError_t rc;
     const bool cartpole = e->cfg.mode == AZG_MODE_DISCRETE;   // the discrete family's kernels (CartPole, MountainCar)
-    if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : azg_ls_dispatch_pendulum(e);
+    const bool mcc = e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT;   // the continuous family whose episodes end (env.cuh: EnvFamily)
+    if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : (mcc ? azg_ls_dispatch_mcc(e) : azg_ls_dispatch_pendulum(e));
     else if (cartpole) rc = azg_dispatch_cartpole(e);
+    else if (mcc) rc = azg_dispatch_mcc(e);
     else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -856,7 +860,8 @@ int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
-    const int env = e->cfg.mode == AZG_MODE_DISCRETE ? 0 : 2;   // (ENV = 0: the discrete family, ENV = 2: both Pendulum versions)
+    // (ENV = 0: the discrete family, ENV = 2: both Pendulum versions, ENV = 4: MountainCarContinuous)
+    const int env = e->cfg.mode == AZG_MODE_DISCRETE ? 0 : (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT ? 4 : 2);
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
     int w = 0;
     switch (e->kernel_form) {

@@ -102,6 +102,9 @@ struct azg_engine {
 hipError_t azg_dispatch_cartpole(azg_engine* e);
 hipError_t azg_dispatch_pendulum_small(azg_engine* e);   // hidden width (padded) <= 128
 hipError_t azg_dispatch_pendulum_large(azg_engine* e);   // 256 and wider
+hipError_t azg_dispatch_mcc(azg_engine* e);              // MountainCarContinuous (continuous MCTS with terminal nodes), all widths
+hipError_t azg_ls_dispatch_mcc(azg_engine* e);
+hipError_t azg_team_dispatch_mcc(azg_engine* e);
 hipError_t azg_ls_dispatch_cartpole(azg_engine* e);      // lock-step path (lockstep.cuh), buffers prepared by the caller
 hipError_t azg_ls_dispatch_pendulum(azg_engine* e);
 // the same search as ONE persistent launch (team.cuh); hipErrorNotReady: its workgroups cannot all be resident, use the launches

@@ -84,7 +84,8 @@ static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
 template <int ENV, int HP, bool GMM>
 static hipError_t ls_run(azg_engine* e) {
     if (e->opt.ls_team) {
-        hipError_t rc = ENV == AZG_ENV_CARTPOLE ? azg_team_dispatch_cartpole(e) : azg_team_dispatch_pendulum(e);
+        hipError_t rc = ENV == AZG_ENV_CARTPOLE ? azg_team_dispatch_cartpole(e)
+                                                : (ENV == AZG_ENV_MOUNTAINCAR_CONT ? azg_team_dispatch_mcc(e) : azg_team_dispatch_pendulum(e));
         if (rc != hipErrorNotReady) return rc;
     }
     e->kernel_form = 1;

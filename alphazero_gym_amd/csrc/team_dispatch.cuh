@@ -57,7 +57,7 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
 // then four per CU with short chunks for larger batches (HP = 1024, LDS trees: the shapes that were measured).
 template <int ENV, int HP, bool GMM, int TLDS>
 static hipError_t team_launch(azg_engine* e) {
-    constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV != AZG_ENV_CARTPOLE;
+    constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
     hipError_t rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, WIDE && e->opt.team_wide);
     if constexpr (WIDE) {
         if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);

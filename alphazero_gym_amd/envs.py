@@ -2,7 +2,7 @@
 
 The reference gets its environments from the third-party ``gym`` package (``rl/make_game.py:49-68``,
 ``gym==0.19.0`` in requirements.txt:10), which is neither vendored in the reference nor installed here.
-These classes restate the published CartPole / MountainCar / Pendulum dynamics with the gym 0.19 ``Env`` call
+These classes restate the published CartPole / MountainCar / MountainCarContinuous / Pendulum dynamics with the gym 0.19 ``Env`` call
 surface the reference's MCTS uses: ``copy.deepcopy(Env)`` + ``Env.step(action)`` returning
 ``(obs, reward, done, info)`` (alphazero/search/mcts.py:443-449, 680-687), ``Env.reset()``, ``Env.seed()``.
 
@@ -19,6 +19,7 @@ ENV_CARTPOLE = 0
 ENV_PENDULUM_V0 = 1
 ENV_PENDULUM_V1 = 2
 ENV_MOUNTAINCAR = 3
+ENV_MOUNTAINCAR_CONT = 4
 
 
 class _Box:
@@ -141,6 +142,63 @@ class MountainCarEnv(_EnvBase):
         return np.array(self.state, dtype=np.float32), -1.0, done, {}
 
 
+class MountainCarContinuousEnv(_EnvBase):
+    """gym ``MountainCarContinuous-v0`` (``Continuous_MountainCarEnv``): one continuous action in [-1, 1], episodes END at the flag
+    (position >= 0.45 with velocity >= 0) -- the env through which the continuous search meets terminal nodes (mcts.py:619-623,
+    682).  gym 0.19's step on python floats: ``force = min(max(action[0], -1), 1)``; ``velocity += force * power - 0.0025 *
+    cos(3 * position)``, clipped to +-0.07; ``position += velocity``, clipped to [-1.2, 0.6]; inelastic wall on the left;
+    ``reward = 100 * done - 0.1 * action[0] ** 2`` (the action as it came, not the clipped force).
+
+    Two deliberate choices, as for Pendulum: the float32 action is widened to float64 before it enters the arithmetic, and the
+    reward is returned as a float64 array of shape (1,) -- the same container PendulumEnv uses.  gym hands back a python float
+    here; under NumPy >= 2 (NEP 50) a python float is "weak", ``node.r + gamma * R`` with a float32 ``R`` (mcts.py:262) would then
+    be a float32 sum and every W / Q of the tree would silently live in float32.  The float64 array keeps the reference's
+    statistics in float64 and Q in shape (K, 1), identical to what the Pendulum goldens pin."""
+
+    azg_env_id = ENV_MOUNTAINCAR_CONT
+    min_action = -1.0
+    max_action = 1.0
+    min_position = -1.2
+    max_position = 0.6
+    max_speed = 0.07
+    goal_position = 0.45
+    goal_velocity = 0.0
+    power = 0.0015
+
+    def __init__(self, state=None):
+        low = np.array([self.min_position, -self.max_speed], dtype=np.float32)
+        high = np.array([self.max_position, self.max_speed], dtype=np.float32)
+        self.observation_space = _Box(low, high, (2,))
+        self.action_space = _Box(self.min_action, self.max_action, (1,))
+        self.seed(None)
+        self.state = None if state is None else np.asarray(state, dtype=np.float64)
+
+    def reset(self):
+        self.state = np.array([self.np_random.uniform(low=-0.6, high=-0.4), 0.0])
+        return np.array(self.state)
+
+    def step(self, action):
+        position, velocity = (float(v) for v in self.state)
+        a = float(np.asarray(action, dtype=np.float32).reshape(-1)[0])
+        force = min(max(a, self.min_action), self.max_action)
+        velocity = velocity + (force * self.power - 0.0025 * math.cos(3 * position))
+        if velocity > self.max_speed:
+            velocity = self.max_speed
+        if velocity < -self.max_speed:
+            velocity = -self.max_speed
+        position = position + velocity
+        if position > self.max_position:
+            position = self.max_position
+        if position < self.min_position:
+            position = self.min_position
+        if position == self.min_position and velocity < 0:
+            velocity = 0.0
+        done = bool(position >= self.goal_position and velocity >= self.goal_velocity)
+        reward = (100.0 if done else 0.0) - (a * a) * 0.1
+        self.state = np.array([position, velocity])
+        return np.array(self.state), np.array([reward]), done, {}
+
+
 class PendulumEnv(_EnvBase):
     """gym ``Pendulum-v0`` (``version=0``: speed clipped after integrating theta) / ``Pendulum-v1`` (clipped before)."""
 
@@ -198,7 +256,9 @@ def make_game(game: str):
         return PendulumEnv(version=0 if game.endswith("v0") else 1)
     if name == "mountaincar":
         return MountainCarEnv()
-    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole, MountainCar and Pendulum only")
+    if name == "mountaincarcontinuous":
+        return MountainCarContinuousEnv()
+    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole, MountainCar(Continuous) and Pendulum only")
 
 
 class VecPendulum:
@@ -234,6 +294,41 @@ class VecPendulum:
             nthd = np.clip(nthd, -8.0, 8.0)
         self.state = np.stack([nth, nthd], 1)
         return -costs, np.zeros(self.n, bool)
+
+
+class VecMountainCarContinuous:
+    """B MountainCarContinuous environments stepped together (numpy float64, same operation order as MountainCarContinuousEnv.step)."""
+
+    azg_env_id = ENV_MOUNTAINCAR_CONT
+
+    def __init__(self, n: int, seed: int = 0):
+        self.n = n
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros((n, 2))
+        self.reset(np.ones(n, bool))
+
+    def reset(self, mask):
+        k = int(mask.sum())
+        if k:
+            self.state[mask] = np.stack([self.rng.uniform(low=-0.6, high=-0.4, size=k), np.zeros(k)], 1)
+
+    def obs(self):
+        return self.state.astype(np.float32)
+
+    def step(self, action):
+        x, v = self.state[:, 0], self.state[:, 1]
+        a = np.asarray(action, np.float32).reshape(-1).astype(np.float64)
+        force = np.minimum(np.maximum(a, -1.0), 1.0)
+        v = v + (force * 0.0015 - 0.0025 * np.cos(3 * x))
+        v = np.where(v > 0.07, 0.07, v)
+        v = np.where(v < -0.07, -0.07, v)
+        x = x + v
+        x = np.where(x > 0.6, 0.6, x)
+        x = np.where(x < -1.2, -1.2, x)
+        v = np.where((x == -1.2) & (v < 0), 0.0, v)
+        done = (x >= 0.45) & (v >= 0.0)
+        self.state = np.stack([x, v], 1)
+        return np.where(done, 100.0, 0.0) - (a * a) * 0.1, done
 
 
 class VecCartPole:

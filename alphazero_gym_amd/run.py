@@ -18,7 +18,7 @@ import torch
 from . import _capi, distributed as D
 from .agent.agents import ContinuousAgent, DiscreteAgent
 from .agent.buffers import DeviceReplay, ReplayBuffer
-from .envs import VecCartPole, VecPendulum, make_game
+from .envs import VecCartPole, VecMountainCarContinuous, VecPendulum, make_game
 from .helpers import check_space, stable_normalizer
 from .search.mcts import BatchedMCTS
 
@@ -135,14 +135,17 @@ class BatchedSelfPlay:
                  c_pw: float = 1.0, kappa: float = 0.5, V_target_policy: str = "off_policy", max_episode_length: int = 200,
                  temperature: float = 1.0, seed: int = 34, rank: int = 0, world: int = 1, device_id: int = 0):
         self.policy = policy
-        self.continuous = game.lower().startswith("pendulum")
+        self.continuous = game.lower().startswith(("pendulum", "mountaincarcontinuous"))
         self.n = n_games
         self.max_len = max_episode_length
         self.temperature = temperature
         self.rng = np.random.RandomState(seed + 1000 * rank)
         base = rank * n_games
         if self.continuous:
-            self.env = VecPendulum(n_games, version=0 if game.endswith("v0") else 1, seed=seed + rank)
+            if game.lower().startswith("mountaincarcontinuous"):
+                self.env = VecMountainCarContinuous(n_games, seed=seed + rank)
+            else:
+                self.env = VecPendulum(n_games, version=0 if game.endswith("v0") else 1, seed=seed + rank)
             self.mcts = BatchedMCTS(policy, env_id=self.env.azg_env_id, mode=_capi.MODE_CONTINUOUS, n_trees=n_games, n_rollouts=n_rollouts,
                                     c_uct=c_uct, gamma=gamma, epsilon=epsilon, c_pw=c_pw, kappa=kappa, V_target_policy=V_target_policy,
                                     action_bound=float(policy.action_bound), seed=seed, tree_id_base=base, device_id=device_id)
@@ -195,14 +198,17 @@ class DeviceSelfPlay:
                  c_pw: float = 1.0, kappa: float = 0.5, V_target_policy: str = "off_policy", max_episode_length: int = 200,
                  deterministic: bool = False, capacity_steps: int = 64, seed: int = 34, rank: int = 0, device_id: int = 0,
                  final_selection: str = "max_visit", temperature: float = 1.0, agent_epsilon: float = 0.0, fifo: bool = False):
-        self.continuous = game.lower().startswith("pendulum")
+        self.continuous = game.lower().startswith(("pendulum", "mountaincarcontinuous"))
         if self.continuous:
-            env_id = _capi.ENV_PENDULUM_V0 if game.endswith("v0") else _capi.ENV_PENDULUM_V1
+            if game.lower().startswith("mountaincarcontinuous"):
+                env_id = _capi.ENV_MOUNTAINCAR_CONT
+            else:
+                env_id = _capi.ENV_PENDULUM_V0 if game.endswith("v0") else _capi.ENV_PENDULUM_V1
             self.mcts = BatchedMCTS(policy, env_id=env_id, mode=_capi.MODE_CONTINUOUS, n_trees=n_games, n_rollouts=n_rollouts, c_uct=c_uct,
                                     gamma=gamma, epsilon=epsilon, c_pw=c_pw, kappa=kappa, V_target_policy=V_target_policy,
                                     action_bound=float(policy.action_bound), seed=seed, tree_id_base=rank * n_games, device_id=device_id)
         else:
-            env_id = _capi.ENV_MOUNTAINCAR if game.lower().startswith("mountaincar") else _capi.ENV_CARTPOLE
+            env_id = _capi.ENV_MOUNTAINCAR if game.lower().startswith("mountaincar") else _capi.ENV_CARTPOLE   # (MountainCar-v0)
             self.mcts = BatchedMCTS(policy, env_id=env_id, mode=_capi.MODE_DISCRETE, n_trees=n_games, n_rollouts=n_rollouts,
                                     c_uct=c_uct, gamma=gamma, epsilon=epsilon, num_actions=policy.num_actions,
                                     V_target_policy=V_target_policy, seed=seed, tree_id_base=rank * n_games, device_id=device_id)

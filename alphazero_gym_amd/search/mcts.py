@@ -28,11 +28,14 @@ def env_signature(env) -> Tuple[int, np.ndarray]:
         return _capi.ENV_CARTPOLE, np.asarray(u.state, dtype=np.float64)
     if name == "MountainCarEnv":
         return _capi.ENV_MOUNTAINCAR, np.asarray(u.state, dtype=np.float64)
+    if name == "Continuous_MountainCarEnv":
+        return _capi.ENV_MOUNTAINCAR_CONT, np.asarray(u.state, dtype=np.float64)
     if name == "PendulumEnv":
         spec = getattr(getattr(u, "spec", None), "id", "") or ""
         return (_capi.ENV_PENDULUM_V0 if spec.endswith("v0") else _capi.ENV_PENDULUM_V1), np.asarray(u.state, dtype=np.float64)
     raise NotImplementedError(
-        f"{name}: the engine steps CartPole, MountainCar and Pendulum in closed form on the GPU; other environments are not supported")
+        f"{name}: the engine steps CartPole, MountainCar, MountainCarContinuous and Pendulum in closed form on the GPU; other "
+        "environments are not supported")
 
 
 def _weights_version(model) -> Tuple:
@@ -232,7 +235,9 @@ class MCTSDiscrete(MCTS):
 
 
 class MCTSContinuous(MCTS):
-    """mcts.py:529-741: progressive widening; a new root every search (no tree reuse)."""
+    """mcts.py:529-741: progressive widening; a new root every search (no tree reuse).  Nodes of environments whose episodes end
+    (MountainCarContinuous) are terminal as in mcts.py:619-623, 682: value 0, no evaluation, the trace stops there; a terminal root
+    state raises ValueError (mcts.py:599-600)."""
 
     _mode = _capi.MODE_CONTINUOUS
 
@@ -259,8 +264,12 @@ class MCTSContinuous(MCTS):
         if len(self._envs) == 1 and self.root_state is not None:
             state = self.root_state
         else:
-            th, thdot = env_signature(self._envs[i])[1]
-            state = np.array([np.cos(th), np.sin(th), thdot])
+            env_id, st = env_signature(self._envs[i])
+            if env_id == _capi.ENV_MOUNTAINCAR_CONT:
+                state = np.array(st)                       # (position, velocity): the observation is the state
+            else:
+                th, thdot = st
+                state = np.array([np.cos(th), np.sin(th), thdot])
         actions = r["actions"][i, :k].copy()
         if k == 1:
             actions = actions.reshape(())   # np.squeeze of a single action (mcts.py:307)

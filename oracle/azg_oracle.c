@@ -125,14 +125,14 @@ const char* azo_last_error(const azg_engine* e) { return e ? e->err : g_create_e
 /* ------------------------------------------------------------------ environments (float64) */
 
 static int env_state_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : 2; }
-static int env_obs_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : (env == AZG_ENV_MOUNTAINCAR ? 2 : 3); }
+static int env_obs_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : ((env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3); }
 static int env_is_discrete(int env) { return env == AZG_ENV_CARTPOLE || env == AZG_ENV_MOUNTAINCAR; }
 static int env_num_actions(int env) { return env == AZG_ENV_CARTPOLE ? 2 : (env == AZG_ENV_MOUNTAINCAR ? 3 : 0); }
 
 static void env_obs(int env, const double* s, float* obs) {
     if (env == AZG_ENV_CARTPOLE) {
         for (int i = 0; i < 4; ++i) obs[i] = (float)s[i];
-    } else if (env == AZG_ENV_MOUNTAINCAR) {
+    } else if (env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_MOUNTAINCAR_CONT) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
     } else {
         double sn, cs;
@@ -181,6 +181,30 @@ static void mountaincar_step(const double* s, int action, double* o, double* rew
     *reward = -1.0;
 }
 
+/* gym Continuous_MountainCarEnv.step (MountainCarContinuous-v0; third-party gym, restated like the others -- envs.py
+ * MountainCarContinuousEnv is the definition): force = clip(action, -1, 1); velocity += force * power - 0.0025 * cos(3 x), clipped;
+ * x += velocity, clipped to [-1.2, 0.6]; inelastic wall on the left; done at x >= 0.45 with velocity >= 0;
+ * reward = 100 * done - 0.1 * action^2 (the action as it came).  The float32 action is widened to float64. */
+static void mountaincar_cont_step(const double* s, float action, double* o, double* reward, int* done) {
+    const double min_position = -1.2, max_position = 0.6, max_speed = 0.07, goal_position = 0.45, goal_velocity = 0.0, power = 0.0015;
+    double position = s[0], velocity = s[1];
+    const double a = (double)action;
+    const double force = a < -1.0 ? -1.0 : (a > 1.0 ? 1.0 : a);
+    double sn, cs;
+    azg_sincos(3.0 * position, &sn, &cs);
+    velocity = velocity + (force * power - 0.0025 * cs);
+    velocity = velocity > max_speed ? max_speed : velocity;
+    velocity = velocity < -max_speed ? -max_speed : velocity;
+    position = position + velocity;
+    position = position > max_position ? max_position : position;
+    position = position < min_position ? min_position : position;
+    if (position == min_position && velocity < 0.0) velocity = 0.0;
+    const int d = (position >= goal_position) && (velocity >= goal_velocity);
+    o[0] = position; o[1] = velocity;
+    *done = d;
+    *reward = (d ? 100.0 : 0.0) - (a * a) * 0.1;
+}
+
 /* gym PendulumEnv.step (v0: clip after integrating theta; v1: clip before); the float32 action is widened to float64 */
 static void pendulum_step(int v1, const double* s, float action, double* o, double* reward, int* done) {
     const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
@@ -209,6 +233,7 @@ static void pendulum_step(int v1, const double* s, float action, double* o, doub
 
 static int env_root_terminal(int env, const double* s) {
     if (env == AZG_ENV_MOUNTAINCAR) return s[0] >= 0.5 && s[1] >= 0.0;
+    if (env == AZG_ENV_MOUNTAINCAR_CONT) return s[0] >= 0.45 && s[1] >= 0.0;
     if (env != AZG_ENV_CARTPOLE) return 0;
     const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
     return (s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr);
@@ -370,7 +395,7 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(NULL, AZG_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(NULL, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(NULL, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > 3) return fail(NULL, AZG_E_INVALID, "unknown env_id");
+    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_MOUNTAINCAR_CONT) return fail(NULL, AZG_E_INVALID, "unknown env_id");
     if (cfg->mode == AZG_MODE_DISCRETE && !env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole)");
     if (cfg->mode == AZG_MODE_CONTINUOUS && env_is_discrete(cfg->env_id))
@@ -660,6 +685,7 @@ static void search_tree(ctx_t* c, const double* root, int carry) {
             const double* s = t->state + (size_t)node * e->S_env;
             if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(s, (int)t->edge_action[k], ns, &r, &done);
             else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(s, (int)t->edge_action[k], ns, &r, &done);
+            else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(s, t->edge_action[k], ns, &r, &done);
             else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, s, t->edge_action[k], ns, &r, &done);
             if (e->cfg.mode == AZG_MODE_CONTINUOUS) r = r / e->cfg.reward_scale;   /* mcts.py:687 */
             make_node(c, k, ns, r, done);
@@ -955,6 +981,7 @@ int azo_selfplay_step(azg_engine* e) {
         int done;
         if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(root, pick, ns, &r, &done);
         else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(root, pick, ns, &r, &done);
+        else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(root, t->edge_action[krec], ns, &r, &done);
         else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, root, t->edge_action[krec], ns, &r, &done);
         e->sp_ret[i] = e->sp_ret[i] + r;
         e->sp_t[i] += 1;
@@ -1104,6 +1131,7 @@ int azo_env_step(int env_id, const double* state, float action, double* next, do
     int d = 0;
     if (env_id == AZG_ENV_CARTPOLE) cartpole_step(state, (int)action, next, reward, &d);
     else if (env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(state, (int)action, next, reward, &d);
+    else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(state, action, next, reward, &d);
     else if (env_id == AZG_ENV_PENDULUM_V0 || env_id == AZG_ENV_PENDULUM_V1) pendulum_step(env_id == AZG_ENV_PENDULUM_V1, state, action, next, reward, &d);
     else return AZG_E_INVALID;
     *done = d;

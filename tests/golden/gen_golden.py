@@ -74,7 +74,7 @@ from alphazero.network.policies import make_policy  # noqa: E402
 
 import oracle_lib as O  # noqa: E402
 from alphazero_gym_amd import _capi  # noqa: E402
-from alphazero_gym_amd.envs import CartPoleEnv, MountainCarEnv, PendulumEnv  # noqa: E402
+from alphazero_gym_amd.envs import CartPoleEnv, MountainCarContinuousEnv, MountainCarEnv, PendulumEnv  # noqa: E402
 
 torch.set_num_threads(1)
 TIES = {"n": 0}
@@ -198,7 +198,7 @@ def dump_reference_tree(root, R):
 def run_t1(case):
     """One T1 case: several independent trees, one reference MCTS object per tree."""
     cont = case["mode"] == 1
-    in_dim = 3 if cont else (2 if case["env_id"] == 3 else 4)
+    in_dim = (2 if case["env_id"] == 4 else 3) if cont else (2 if case["env_id"] == 3 else 4)
     n_dist = 2 if cont else case["num_actions"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
                          gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0),
@@ -213,7 +213,10 @@ def run_t1(case):
     roots = np.asarray(case["roots"], dtype=np.float64)
     for ti, root in enumerate(roots):
         tree_id = case.get("tree_id_base", 0) + ti
-        if cont:
+        if cont and case["env_id"] == 4:
+            env = MountainCarContinuousEnv(state=root)      # episodes end: terminal nodes in the continuous search
+            root_obs = np.array(env.state)
+        elif cont:
             env = PendulumEnv(state=root, version=1 if case["env_id"] == 2 else 0)
             root_obs = env._get_obs()
         else:
@@ -298,6 +301,18 @@ T1_CASES = {
     "t1_mountaincar_default": dict(env_id=3, mode=0, num_actions=3, n_sims=90, c_uct=0.8, gamma=0.99, epsilon=0.0,
                                    v_target="off_policy", hidden=[64, 64], act="relu", wseed=17, seed=21, wscale=2.0,
                                    roots=[[-0.5, 0.0], [0.43, 0.035], [-1.19, -0.03], [0.3, 0.05]]),
+    # MCTSContinuous over an env whose episodes END (mcts.py:619-623 V = 0 for a terminal node, 682 `while not node.terminal`):
+    # gym MountainCarContinuous-v0, action bound 1.  Roots one step from the flag (every child terminal: the whole search is traces
+    # that end in existing terminal nodes), two and a few steps away (terminal nodes deeper in the tree), in the valley (none) and
+    # running into the left wall; the second case discounts, explores with epsilon-greedy and another widening law (c_pw <= 1: with
+    # c_pw > 1 the first trace widens the root again and leaves the root's initial action unvisited with a 0-d Q next to (1,)-shaped
+    # ones, which the reference's own np.array(UCT) cannot stack under NumPy 2).
+    "t1_mcc_terminal": dict(env_id=4, mode=1, n_sims=120, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0.0, v_target="off_policy",
+                            hidden=[64, 64], act="elu", wseed=41, seed=43, wscale=2.0, action_bound=1.0,
+                            roots=[[0.43, 0.03], [0.385, 0.04], [0.30, 0.055], [-0.5, 0.0], [-1.19, -0.04]]),
+    "t1_mcc_terminal_eps": dict(env_id=4, mode=1, n_sims=90, c_uct=0.3, c_pw=0.9, kappa=0.65, gamma=0.97, epsilon=0.2,
+                                v_target="on_policy", hidden=[128, 128], act="relu", wseed=42, seed=44, wscale=3.0, action_bound=1.0,
+                                tree_id_base=300, search_idx=2, roots=[[0.40, 0.045], [0.34, 0.06], [0.25, 0.065]]),
     "t1_mountaincar_epsgreedy_reuse": dict(env_id=3, mode=0, num_actions=3, n_sims=40, c_uct=2.0, gamma=1, epsilon=0.15,
                                            v_target="on_policy", hidden=[128, 128], act="elu", wseed=19, seed=22, wscale=3.0,
                                            reuse_steps=3, roots=[[-0.45, 0.01], [0.41, 0.04]]),
@@ -600,6 +615,7 @@ def _t3_scale_chunk(job):
     torch.set_num_threads(1)
     cont = kind not in ("b", "d", "m")
     car = kind == "m"           # gym MountainCar-v0: three actions, observation = (position, velocity)
+    mcc = kind == "h"           # gym MountainCarContinuous-v0: continuous search with terminal nodes (VERDICT r04 row h)
     gmm = kind == "g"           # the reference's default continuous policy: 2-component mixture (config/policy/ContinuousPolicy.yaml)
     eps = 0.1 if kind == "d" else 0.0   # the reference's default discrete search: epsilon-greedy 0.1 (config/mcts/MCTSDiscrete.yaml)
     if gmm:
@@ -607,6 +623,11 @@ def _t3_scale_chunk(job):
         pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
                           num_components=2, action_bound=2.0)
         set_policy_weights(pol, blob, 3, hidden, 6)
+    elif mcc:
+        blob = O.make_weights(34, 2, hidden, 2)
+        pol = make_policy(representation_dim=2, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
+                          num_components=1, action_bound=1.0)
+        set_policy_weights(pol, blob, 2, hidden, 2)
     elif cont:
         blob = O.make_weights(34, 3, hidden, 2)
         pol = make_policy(representation_dim=3, action_dim=1, distribution="normal", hidden_dimensions=hidden, nonlinearity="elu",
@@ -654,7 +675,11 @@ def _t3_scale_chunk(job):
                 RM.random = EngineRandom(seed, ti, 0)
             COUNTER["n"] = 0
             del log[:]
-            if cont:
+            if mcc:
+                env = MountainCarContinuousEnv(state=roots[ti - lo])
+                m = RM.MCTSContinuous(model=pol, n_rollouts=n_rollouts, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                                      V_target_policy="off_policy", device="cpu", root_state=np.array(env.state))
+            elif cont:
                 env = PendulumEnv(state=roots[ti - lo], version=1)
                 m = RM.MCTSContinuous(model=pol, n_rollouts=n_rollouts, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
                                       V_target_policy="off_policy", device="cpu", root_state=env._get_obs())
@@ -687,7 +712,19 @@ T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engi
     "d": (0, 0, [128, 128], "relu", 8, 1024, dict(c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1)),
     # three actions end to end: gym MountainCar-v0 with the reference's DiscretePolicy (2x64 ReLU), 60 rollouts, gamma 0.99
     "m": (3, 0, [64, 64], "relu", 60, 1024, dict(c_uct=0.8, gamma=0.99, num_actions=3)),
+    # the continuous search over an env whose episodes end (mcts.py:619-623, 682): gym MountainCarContinuous-v0 with the reference's
+    # DiagonalNormalPolicy (2x256 ELU, action bound 1), 120 rollouts, roots on the slope below the flag (mcc_scale_roots)
+    "h": (4, 1, [256, 256], "elu", 120, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, action_bound=1.0)),
 }
+
+
+def mcc_scale_roots(synthetic):
+    """Roots of the MountainCarContinuous leg: the engine's synthetic roots start in the valley (position U(-0.6, -0.4), at rest), from
+    where no 120-rollout tree ever reaches the flag.  They are mapped onto the slope below it: u = (position + 0.6) / 0.2 in [0, 1)
+    -> position 0.25 + 0.199 u, velocity 0.02 + 0.05 frac(17 u): a step to a few steps away from the flag at 0.45 (the same formula in
+    tests/test_t3_scale.py)."""
+    u = (np.asarray(synthetic)[:, 0] + 0.6) / 0.2
+    return np.stack([0.25 + 0.199 * u, 0.02 + 0.05 * ((17.0 * u) % 1.0)], 1)
 T3_SCALE_FULL = 1024   # trees per leg whose Q / actions / value target are stored as well (visit counts: every tree)
 
 
@@ -705,8 +742,10 @@ def run_t3_scale(procs=8, only=None):
             continue
         eng = O.OracleEngine(env_id=env_id, mode=mode, n_trees=B, n_sims=n_roll, seed=34, **kw)
         roots = eng.synthetic_roots()
+        if tag == "h":
+            roots = mcc_scale_roots(roots)
         n_dist = 6 if tag == "g" else (3 if tag == "m" else 2)
-        in_dim = 2 if tag == "m" else (4 if mode == 0 else 3)
+        in_dim = 2 if tag in ("m", "h") else (4 if mode == 0 else 3)
         eng.set_weights(_capi.make_desc(in_dim, hidden, n_dist, act, num_components=2 if tag == "g" else 0),
                         O.make_weights(35 if tag == "g" else 34, in_dim, hidden, n_dist))
         eng.trace_enable()
@@ -989,6 +1028,11 @@ T7_CASES = {
                               hidden=[64], act="relu", wseed=8, wscale=2.0, seed=16, tree_id_base=0, n_games=3, n_steps=10, max_len=7,
                               det=False, final_selection="max_value"),
     # three actions (gym MountainCar-v0): sampled final action, tree reuse through mcts_forward, episodes cut by length
+    # MountainCarContinuous: the first episode of a game starts below the flag (first_roots, uploaded after selfplay_begin), so
+    # that episodes END by reaching it (+100) and by length; searches meet terminal nodes; later episodes start in the valley
+    "mcc": dict(env_id=4, mode=1, n_sims=24, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0.0, v_target="off_policy",
+                hidden=[64, 64], act="elu", wseed=10, wscale=2.0, seed=18, tree_id_base=7, n_games=4, n_steps=10, max_len=6,
+                action_bound=1.0, first_roots=[[0.41, 0.04], [0.33, 0.06], [0.36, 0.02], [-0.5, 0.0]]),
     "mountaincar_sampled": dict(env_id=3, mode=0, num_actions=3, n_sims=18, c_uct=2.0, gamma=0.98, epsilon=0.0, v_target="off_policy",
                                 hidden=[64, 64], act="relu", wseed=9, wscale=3.0, seed=17, tree_id_base=3, n_games=3, n_steps=16, max_len=7,
                                 det=False),
@@ -1003,12 +1047,15 @@ def run_t7(case):
     import alphazero.agent.agents as RA
     from alphazero.agent.buffers import ReplayBuffer
     cont = case["mode"] == 1
-    in_dim = 3 if cont else (2 if case["env_id"] == 3 else 4)
+    mcc = case["env_id"] == 4
+    bound = case.get("action_bound", 2.0)
+    in_dim = (2 if mcc else 3) if cont else (2 if case["env_id"] == 3 else 4)
     n_dist = 2 if cont else case["num_actions"]
     seed = case["seed"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
                          gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0),
-                         c_pw=case.get("c_pw", 1.0), kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=seed)
+                         c_pw=case.get("c_pw", 1.0), kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=seed,
+                         action_bound=bound)
     eng.set_weights(_capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]),
                     O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0)))
     K, So = eng.kmax, eng.s_obs
@@ -1046,7 +1093,7 @@ def run_t7(case):
             gt = case["tree_id_base"] + g
             step_box["gt"] = gt
             if cont:
-                env = PendulumEnv(version=1 if case["env_id"] == 2 else 0)
+                env = MountainCarContinuousEnv() if mcc else PendulumEnv(version=1 if case["env_id"] == 2 else 0)
                 ag = object.__new__(RA.ContinuousAgent)
                 ag.final_selection = fs; ag.epsilon = case.get("agent_eps", 0)
                 ag.mcts = RM.MCTSContinuous(model=None, n_rollouts=case["n_sims"], c_uct=case["c_uct"], c_pw=case["c_pw"],
@@ -1064,13 +1111,15 @@ def run_t7(case):
             while step < n_steps:
                 # Env.reset() (run_*.py: `state = Env.reset()`), with the engine's reset state of (game, episode)
                 rs = O.reset_state(seed, gt, episode, not cont, env_id=case["env_id"])
+                if episode == 0 and "first_roots" in case:
+                    rs = np.asarray(case["first_roots"][g], np.float64)   # (the test uploads these roots after selfplay_begin)
                 env.state = np.asarray(rs, np.float64) if cont else tuple(float(v) for v in rs)
-                state = env._get_obs() if cont else np.array(env.state, dtype=np.float32)
+                state = (np.array(env.state) if mcc else env._get_obs()) if cont else np.array(env.state, dtype=np.float32)
                 R = 0.0
                 ag.reset_mcts(root_state=state)
                 for t in range(max_len):
                     step_box["step"] = step
-                    ag.mcts.model = OracleModel(eng, seed, gt, step, 2.0)
+                    ag.mcts.model = OracleModel(eng, seed, gt, step, bound)
                     RM.random = EngineRandom(seed, gt, step)
                     COUNTER["n"] = 0
                     root_before[step, g] = env.azg_state()

@@ -136,7 +136,22 @@ CONFIGS = [
     (3, 0, [256, 256], "relu", 50, dict(c_uct=1.5, gamma=0.97, num_actions=3)),
     (3, 0, [512, 512], "relu", 25, dict(c_uct=1.5, gamma=1.0, num_actions=3)),
     (3, 0, [64], "relu", 200, dict(c_uct=3.0, gamma=0.98, num_actions=3, v_target="greedy")),
+    # MCTSContinuous over an env whose episodes END (gym MountainCarContinuous-v0; mcts.py:619-623, 682): terminal nodes in the continuous
+    # descent -- 4-wave LDS kernels, the 8-wave shapes of 2x256 networks (lean walkers), a mixture head, a wide network (team kernel /
+    # per-layer launches / one-launch kernel), trees in global memory (> 255 records), > 16 children per node
+    (4, 1, [64, 64], "elu", 120, dict(c_uct=0.05, gamma=1.0, action_bound=1.0)),
+    (4, 1, [256, 256], "elu", 150, dict(c_uct=0.1, gamma=0.98, epsilon=0.15, v_target="on_policy", action_bound=1.0)),
+    (4, 1, [128, 128, 128], "elu", 60, dict(c_uct=0.05, gamma=1.0, action_bound=1.0, _ncomp=2)),
+    (4, 1, [512, 512], "elu", 30, dict(c_uct=0.05, gamma=1.0, action_bound=1.0)),
+    (4, 1, [64, 64], "relu", 300, dict(c_uct=0.05, gamma=0.99, action_bound=1.0)),
+    (4, 1, [128, 128], "elu", 90, dict(c_uct=0.2, gamma=1.0, c_pw=2.0, kappa=0.6, action_bound=1.0, v_target="greedy")),
 ]
+
+
+def slope_roots(roots):
+    """MountainCarContinuous roots on the slope below the flag (the synthetic ones rest in the valley, out of the flag's reach)."""
+    u = (roots[:, 0] + 0.6) / 0.2
+    return np.stack([0.25 + 0.199 * u, 0.02 + 0.05 * ((17.0 * u) % 1.0)], 1)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
@@ -179,7 +194,7 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
             monkeypatch.setenv("AZG_LS_TEAM", "0")            # the per-layer launches instead of the persistent team kernel
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
-    in_dim, n_dist = (3, 3 * ncomp if ncomp else 2) if mode == 1 else ((2, 3) if env == 3 else (4, 2))
+    in_dim, n_dist = (2 if env == 4 else 3, 3 * ncomp if ncomp else 2) if mode == 1 else ((2, 3) if env == 3 else (4, 2))
     desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
     blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
     if ln:
@@ -193,11 +208,18 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     if env == 3:
         roots[3] = [0.44, 0.04]               # the flag is two steps away
         roots[5] = [-1.195, -0.05]            # into the left wall
+    if env == 4:
+        roots = slope_roots(roots)
+        roots[3] = [0.44, 0.03]               # every action reaches the flag: a search of traces that end in terminal nodes
+        roots[5] = [-1.195, -0.05]            # into the left wall
+        roots[7] = [-0.5, 0.0]                # the valley: no terminal node within reach
     carry = (np.arange(B) % 7).astype(np.int32) if mode == 0 else None
     forms = []
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3, forms=forms)
     b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=3)
     _assert_same(a, b)
+    if env == 4:   # the point of these configurations: terminal nodes, and traces that ended in an existing one (no new record)
+        assert ((a[1]["node_flags"] & 2) != 0).any(1).sum() >= B // 3 and (a[1]["n_records"] < n_sims + 1).sum() >= B // 3
 
 
 def test_deep_discrete_traces(native):
@@ -250,6 +272,13 @@ def test_terminal_root_raises(native):
     e.set_weights(_capi.make_desc(4, [64], 2, "relu"), O.make_weights(1, 4, [64], 2))
     with pytest.raises(ValueError):
         e.search(np.array([[0.0, 0, 0, 0], [3.0, 0, 0, 0]]))
+    e.close()
+    # continuous mode (mcts.py:599-600): a MountainCarContinuous root at the flag
+    e = native.HipEngine(env_id=4, mode=1, n_trees=2, n_sims=4, c_uct=0.05, gamma=1.0, action_bound=1.0)
+    e.set_weights(_capi.make_desc(2, [64], 2, "relu"), O.make_weights(1, 2, [64], 2))
+    with pytest.raises(ValueError):
+        e.search(np.array([[-0.5, 0.0], [0.46, 0.01]]))
+    e.search(np.array([[-0.5, 0.0], [0.46, -0.01]]))    # beyond the flag but rolling back: not terminal (gym: velocity >= 0)
     e.close()
 
 
@@ -501,12 +530,14 @@ def _random_case(rng):
                  v_target=str(rng.choice(["off_policy", "on_policy", "greedy"])))
     ncomp = 0
     if cont:
-        env = int(rng.choice([1, 2]))
+        env = int(rng.choice([1, 2, 4]))   # (4: MountainCarContinuous -- terminal nodes in the continuous search)
         extra.update(c_uct=float(rng.choice([0.02, 0.05, 0.5])), c_pw=float(rng.choice([0.5, 1.0, 1.13, 2.0, 4.0])),
                      kappa=float(rng.choice([0.3, 0.5, 0.75])))
+        if env == 4:
+            extra["action_bound"] = float(rng.choice([1.0, 1.0, 2.0]))
         if rng.random() < 0.25:
             ncomp = int(rng.integers(2, 6))
-        in_dim, n_dist = 3, (3 * ncomp if ncomp else 2)
+        in_dim, n_dist = (2 if env == 4 else 3), (3 * ncomp if ncomp else 2)
         mode = 1
     elif rng.random() < 0.65:
         env, mode, in_dim, n_dist = 0, 0, 4, 2
@@ -548,6 +579,8 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     o = O.OracleEngine(**kw)
     roots = o.synthetic_roots()
     o.close()
+    if env == 4:
+        roots = slope_roots(roots)
     carry = np.minimum(np.arange(B) % 5, 3 * n_sims).astype(np.int32) if mode == 0 else None
     sidx = int(rng.integers(0, 50))
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=sidx)

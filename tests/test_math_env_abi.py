@@ -104,6 +104,43 @@ def test_mountaincar_c_env_matches_python_env():
         assert -0.6 <= s[0] <= -0.4 and s[1] == 0.0
 
 
+def test_mountaincar_continuous_c_env_matches_python_env():
+    """gym MountainCarContinuous-v0: the oracle's step against the Python restatement -- in the valley, at the inelastic left wall,
+    at both speed limits, with actions beyond the [-1, 1] force clip (the reward uses the action as it came) and across the flag at
+    0.45 (done, +100); the VecMountainCarContinuous batch form agrees with both."""
+    from alphazero_gym_amd.envs import MountainCarContinuousEnv, VecMountainCarContinuous
+    rng = np.random.Generator(np.random.PCG64(6))
+    n_done = n_wall = 0
+    S, A, NXT, R, D = [], [], [], [], []
+    for i in range(600):
+        s = np.array([rng.uniform(-1.2, 0.6), rng.uniform(-0.07, 0.07)])
+        if i % 7 == 0:
+            s = np.array([rng.uniform(-1.2, -1.19), rng.uniform(-0.07, 0.0)])    # into the wall
+        if i % 5 == 0:
+            s = np.array([rng.uniform(0.38, 0.45), rng.uniform(0.0, 0.07)])      # up to the flag
+        a = np.float32(rng.uniform(-2.5, 2.5))
+        e = MountainCarContinuousEnv(state=s)
+        obs, r, done, _ = e.step(np.array([a], dtype=np.float32))
+        nxt, rc, dc, obsc = O.env_step(4, s, a)
+        np.testing.assert_allclose(nxt, e.state, rtol=0, atol=1e-15)
+        assert r.shape == (1,) and r.dtype == np.float64 and rc == float(r[0]) and dc == done
+        assert rc == (100.0 if done else 0.0) - float(a) * float(a) * 0.1
+        np.testing.assert_array_equal(obsc, obs.astype(np.float32))
+        n_done += done
+        n_wall += (nxt[0] == -1.2 and nxt[1] == 0.0)
+        S.append(s); A.append(a); NXT.append(nxt); R.append(rc); D.append(done)
+    assert n_done > 30 and n_wall > 10
+    v = VecMountainCarContinuous(len(S))
+    v.state = np.array(S)
+    rv, dv = v.step(np.array(A))
+    np.testing.assert_allclose(v.state, np.array(NXT), rtol=0, atol=1e-15)   # (numpy's vector cos and libm's differ by an ulp now and then)
+    np.testing.assert_array_equal(rv, np.array(R))
+    np.testing.assert_array_equal(dv, np.array(D))
+    for ep in range(5):
+        s = O.reset_state(9, 3, ep, False, env_id=4)
+        assert -0.6 <= s[0] <= -0.4 and s[1] == 0.0
+
+
 def test_hip_library_exports_every_symbol_of_the_header():
     """The drop-in boundary: every entry point declared in include/azgym.h must be exported by libazgym_hip.so
     (loading needs no GPU; no compute is called)."""

@@ -32,6 +32,36 @@ def test_run_continuous_agent_two_short_episodes(backend):
     assert all(np.isfinite(float(v)) for v in logs[-1].values())
 
 
+def test_run_continuous_agent_on_mountaincar_continuous(backend):
+    """run_continuous.py's loop with `game: MountainCarContinuous-v0` (VERDICT r04 row h): the action bound comes from the env's action
+    space (1.0), the observation is (position, velocity), every step costs 0.1 a^2; and a ContinuousAgent.act on a state one step
+    below the flag searches a tree of terminal nodes (mcts.py:619-623, 682), a state AT the flag raises ValueError (599-600)."""
+    from alphazero_gym_amd.envs import MountainCarContinuousEnv
+    from alphazero_gym_amd.agent.agents import ContinuousAgent
+    torch.manual_seed(0)
+    rets = run.run_continuous_agent(dict(game="MountainCarContinuous-v0", num_train_episodes=2, max_episode_length=5, mcts=dict(n_rollouts=12),
+                                         policy=dict(hidden_dimensions=[64, 64]), buffer=dict(max_size=50, batch_size=4)))
+    assert len(rets) == 2 and all(-0.5 - 1e-9 <= r <= 0 for r in rets)      # five steps in the valley: -0.1 a^2 each, |a| <= 1
+    pol = dict(_target_="alphazero_gym_amd.network.policies.make_policy", representation_dim=2, action_dim=1, distribution="normal",
+               hidden_dimensions=[64, 64], nonlinearity="elu", num_components=1, action_bound=1.0)
+    mcts = dict(_target_="alphazero_gym_amd.search.mcts.MCTSContinuous", n_rollouts=30, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0,
+                V_target_policy="off_policy", device="cpu", root_state=None)
+    ag = ContinuousAgent(policy_cfg=pol, mcts_cfg=mcts, loss_cfg=run.LOSS_TUNED, optimizer_cfg=run.RMSPROP, final_selection="max_visit",
+                         epsilon=0, train_epochs=1, grad_clip=0, device="cpu")
+    env = MountainCarContinuousEnv(state=[0.44, 0.03])
+    ag.reset_mcts(np.array(env.state))
+    action, s, actions, counts, Qs, V = ag.act(env)
+    assert counts.sum() == 30 and Qs.shape == (len(counts), 1) and abs(float(action[0])) <= 1.0
+    np.testing.assert_array_equal(s, np.array([0.44, 0.03]))
+    # every child of this root is terminal: Q = (100 - 0.1 a^2) / PENDULUM_R_SCALE exactly, whatever the network says
+    np.testing.assert_allclose(Qs[:, 0], (100.0 - 0.1 * actions.astype(np.float64) ** 2) / 16.2736044, rtol=1e-12)
+    _, r, done, _ = env.step(action)
+    assert done and float(r[0]) > 99.0
+    with pytest.raises(ValueError):
+        ag.reset_mcts(np.array(env.state))
+        ag.act(env)                                                         # the env now sits at the flag: a terminal root
+
+
 def test_run_discrete_agent_two_short_episodes(backend):
     torch.manual_seed(0)
     rets = run.run_discrete_agent(dict(num_train_episodes=2, max_episode_length=8, mcts=dict(n_rollouts=8),
@@ -75,6 +105,22 @@ def test_device_selfplay_and_training_round(backend):
     assert np.isfinite(info["loss"]) and any(not torch.equal(a, b) for a, b in zip(before, ag.nn.parameters()))
     rows2 = sp.collect(2)                       # picks up the new weights
     assert rows2.shape[0] == 16 and sp.mean_finished_return() < 0
+
+
+def test_device_selfplay_on_mountaincar_continuous(backend):
+    """DeviceSelfPlay / BatchedSelfPlay with `game="MountainCarContinuous-v0"`: rows of (position, velocity | actions | counts | Q | V)."""
+    torch.manual_seed(0)
+    pol = make_policy(representation_dim=2, action_dim=1, distribution="normal", hidden_dimensions=[64, 64], nonlinearity="elu",
+                      num_components=1, action_bound=1.0)
+    sp = run.DeviceSelfPlay(pol, game="MountainCarContinuous-v0", n_games=6, n_rollouts=16, c_uct=0.05, max_episode_length=3, capacity_steps=4)
+    rows = sp.collect(4)
+    K = 4
+    assert rows.shape == (24, 2 + 3 * K + 1)
+    s, a, c, q, v = D.unpack_replay_rows(rows, 2, K)
+    np.testing.assert_array_equal(c.sum(1), np.full(24, 16.0))
+    assert (np.abs(a) <= 1.0).all() and (s[:, 0] < 0.45).all()
+    hs = run.BatchedSelfPlay(pol, game="MountainCarContinuous-v0", n_games=5, n_rollouts=16, c_uct=0.05, max_episode_length=3)
+    assert hs.collect(4).shape == (20, 2 + 3 * K + 1) and len(hs.finished_returns) == 5
 
 
 def test_device_selfplay_with_three_actions(backend):

@@ -18,7 +18,16 @@ CASES = {
                              desc=(4, [64, 64], 2, "relu"), max_len=6, det=False),
     "cartpole_det": dict(kw=dict(env_id=0, mode=0, n_sims=24, c_uct=20.0, gamma=0.97, num_actions=2, seed=13, v_target="on_policy"),
                          desc=(4, [128, 128], 2, "relu"), max_len=7, det=True),
+    # MountainCarContinuous: games start below the flag (roots uploaded after selfplay_begin), so episodes end by reaching it
+    "mcc": dict(kw=dict(env_id=4, mode=1, n_sims=30, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=14, tree_id_base=9, action_bound=1.0),
+                desc=(2, [64, 64], 2, "elu"), max_len=5, det=False, slope=True),
 }
+
+
+def slope_roots(e):
+    """MountainCar roots on the slope below the flag instead of the valley (the same map as the T3-scale leg's)."""
+    u = (e.synthetic_roots()[:, 0] + 0.6) / 0.2
+    return np.stack([0.25 + 0.199 * u, 0.02 + 0.05 * ((17.0 * u) % 1.0)], 1)
 
 
 def play(engine_cls, case, n_trees=21, steps=9):
@@ -27,6 +36,8 @@ def play(engine_cls, case, n_trees=21, steps=9):
     in_dim, hidden, nd, act = c["desc"]
     e.set_weights(_capi.make_desc(in_dim, hidden, nd, act), O.make_weights(3, in_dim, hidden, nd, scale=2.0))
     e.selfplay_begin(c["max_len"], c["det"], capacity_steps=steps)
+    if c.get("slope"):
+        e.upload_roots(slope_roots(e))
     for _ in range(steps):
         e.selfplay_step()
     rows = e.selfplay_rows(clear=True)
@@ -42,11 +53,15 @@ def test_selfplay_invariants_on_oracle(case):
     c = CASES[case]
     n_sims = c["kw"]["n_sims"]
     K = 6 if c["kw"]["mode"] == 1 else 2    # ceil(sqrt(30)) root children / two CartPole actions
-    so = 3 if c["kw"]["mode"] == 1 else 4
+    so = (2 if case == "mcc" else 3) if c["kw"]["mode"] == 1 else 4
     assert rows.shape == (9 * 21, so + 3 * K + 1)
     counts = rows[:, so + K:so + 2 * K]
     np.testing.assert_array_equal(counts.sum(1), np.full(len(rows), float(n_sims)))
-    if c["kw"]["mode"] == 1:
+    if case == "mcc":
+        reached = fsum > 50                                                  # +100 at the flag
+        assert reached.any() and (fcnt >= 1).all() and (np.abs(rows[:, so:so + K]) <= 1.0).all()   # actions within the bound
+        assert (-0.6 <= state[reached, 0]).all() and (state[:, 0] < 0.45).all()   # a game that reached the flag restarted in the valley
+    elif c["kw"]["mode"] == 1:
         np.testing.assert_allclose(np.hypot(rows[:, 0], rows[:, 1]), 1.0, atol=1e-6)
         assert (fcnt == 9 // c["max_len"]).all() and (fsum < 0).all()       # Pendulum never terminates: episodes end by length
     else:
@@ -114,10 +129,11 @@ def _engine_cls(which):
 
 def _t7_engine(cls, case, **over):
     cont = case["mode"] == 1
-    in_dim, n_dist = (3, 2) if cont else (2 if case["env_id"] == 3 else 4, case["num_actions"])
+    in_dim, n_dist = (2 if case["env_id"] == 4 else 3, 2) if cont else (2 if case["env_id"] == 3 else 4, case["num_actions"])
     e = cls(env_id=case["env_id"], mode=case["mode"], n_trees=case["n_games"], n_sims=case["n_sims"], c_uct=case["c_uct"],
             gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0), c_pw=case.get("c_pw", 1.0),
-            kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=case["seed"], tree_id_base=case["tree_id_base"])
+            kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=case["seed"], tree_id_base=case["tree_id_base"],
+            action_bound=case.get("action_bound", 2.0))
     e.set_weights(_capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]),
                   O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0)))
     kw = dict(max_episode_length=case["max_len"], deterministic=case.get("det", False), capacity_steps=case["n_steps"],
@@ -125,6 +141,8 @@ def _t7_engine(cls, case, **over):
               agent_epsilon=case.get("agent_eps", 0.0))
     kw.update(over)
     e.selfplay_begin(**kw)
+    if "first_roots" in case:   # (the T7 case's games start their first episode here instead of at the engine's reset state)
+        e.upload_roots(np.asarray(case["first_roots"], np.float64))
     return e
 
 

@@ -4,7 +4,9 @@ MCTSContinuous.search / MCTSDiscrete.search (alphazero/search/mcts.py:418-462, 6
 200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
 each -- of the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): the 2-component mixture head on a
 3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`);
-and 1024 trees of gym MountainCar-v0 (three actions) with the reference's DiscretePolicy:
+and 1024 trees of gym MountainCar-v0 (three actions) with the reference's DiscretePolicy; and 1024 trees of gym
+MountainCarContinuous-v0 -- the continuous search over an env whose episodes end (terminal nodes: mcts.py:619-623, 682) -- with the
+reference's DiagonalNormalPolicy:
 tests/golden/t3_scale.npz, written by tests/golden/gen_golden.py `scale` from the imported reference.
 
 The networks differ from torch's by ~1e-7 (summation order), so a selection whose two best scores are closer than that could
@@ -35,11 +37,23 @@ LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims, network ou
     "d": (dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, epsilon=0.1, seed=34), 4, [128, 128], "relu", 8, 2, 0, 34),
     # three actions end to end: gym MountainCar-v0 with the reference's DiscretePolicy (2x64 ReLU), 60 rollouts, gamma 0.99
     "m": (dict(env_id=3, mode=0, c_uct=0.8, gamma=0.99, num_actions=3, seed=34), 2, [64, 64], "relu", 60, 3, 0, 34),
+    # the continuous search over an env whose episodes END (VERDICT r04 row h; mcts.py:619-623, 682): gym MountainCarContinuous-v0 with
+    # the reference's DiagonalNormalPolicy (2x256 ELU, action bound 1), 120 rollouts, roots on the slope below the flag
+    "h": (dict(env_id=4, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, action_bound=1.0, seed=34), 2, [256, 256], "elu", 120, 2, 0, 34),
 }
-N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024 + 1024
+N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024 + 1024 + 1024
+
+
+def mcc_scale_roots(synthetic):
+    """Leg h's roots (the same formula as tests/golden/gen_golden.py mcc_scale_roots): the engine's synthetic MountainCar roots (valley,
+    at rest) mapped onto the slope below the flag, u = (position + 0.6) / 0.2 -> position 0.25 + 0.199 u, velocity 0.02 + 0.05 frac(17 u)."""
+    u = (np.asarray(synthetic)[:, 0] + 0.6) / 0.2
+    return np.stack([0.25 + 0.199 * u, 0.02 + 0.05 * ((17.0 * u) % 1.0)], 1)
+
 NAMES = {"c": "config C", "b": "config B", "e": "config E", "g": "the reference's default continuous setup (mixture head, 25 rollouts)",
          "d": "the reference's default discrete setup (epsilon-greedy 0.1, 8 rollouts)",
-         "m": "MountainCar-v0 (three actions, 60 rollouts)"}
+         "m": "MountainCar-v0 (three actions, 60 rollouts)",
+         "h": "MountainCarContinuous-v0 (continuous search with terminal nodes, 120 rollouts)"}
 
 
 def _network(leg):
@@ -67,7 +81,7 @@ def attribute(tag, tree, ref_leaf, root):
     return d, (float(margin[0, d]) if d >= 0 else float("inf"))
 
 
-def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m")):
+def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m", "h")):
     z = np.load(os.path.join(P.GOLDEN, "t3_scale.npz"))
     total = matched = 0
     lines = []
@@ -76,10 +90,20 @@ def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m")):
         roots = z[f"{tag}_roots"]
         B = len(roots)
         e = engine_cls(n_trees=B, n_sims=n_sims, **kw)
-        np.testing.assert_array_equal(e.synthetic_roots(), roots)      # the fixture's roots are the engine's own synthetic roots 0..B-1
+        # the fixture's roots are the engine's own synthetic roots 0..B-1 (leg h: mapped onto the slope below the flag)
+        np.testing.assert_array_equal(mcc_scale_roots(e.synthetic_roots()) if tag == "h" else e.synthetic_roots(), roots)
         e.set_weights(*_network(LEGS[tag]))
         e.search(roots)
         r = e.results()
+        if tag == "h":
+            # the leg is about terminal nodes: most trees must contain some, and traces that ended in an EXISTING terminal node
+            # created no record (Pendulum: n_records == n_sims + 1 always)
+            d = e.dump_tree()
+            with_terminal = ((d["node_flags"] & 2) != 0).any(1)
+            short = d["n_records"] < n_sims + 1
+            assert with_terminal.mean() > 0.5 and short.mean() > 0.3, (with_terminal.mean(), short.mean())
+            lines.append(f"   leg h: {int(with_terminal.sum())} of {B} trees hold terminal nodes, {int(short.sum())} ran traces that ended in an "
+                         f"existing terminal node ({int((n_sims + 1 - d['n_records']).sum())} such traces in all)")
         e.close()
         K = z[f"{tag}_counts"].shape[1]
         ref_counts = z[f"{tag}_counts"].astype(np.int32)
