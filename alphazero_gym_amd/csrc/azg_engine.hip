@@ -229,6 +229,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.force_persistent = env_digit("AZG_FORCE_PERSISTENT", 0) == 1;
     e->opt.force_stream_weights = env_digit("AZG_FORCE_STREAM_WEIGHTS", 0) == 1;
     e->opt.force_global_tree = env_digit("AZG_FORCE_GLOBAL_TREE", 0) == 1;
+    e->opt.no_spec = env_digit("AZG_NO_SPEC", 0) == 1;
     e->opt.waves = env_digit("AZG_WAVES", 0);
     e->opt.groups = env_digit("AZG_GROUPS", 0);
     { const char* v = getenv("AZG_TRACE_CAP"); const int t = v ? atoi(v) : 0; e->opt.trace_cap = t > 0 ? t : 0; }
@@ -282,7 +283,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->dyn_lds = 0;
     DeviceScope scope(cfg->device_id);
     if (!scope.ok) { delete e; return fail(nullptr, AZG_E_DEVICE, "hipSetDevice failed"); }
-    e->waves = 4; e->groups = 1; e->tile_trees = 16; e->n_cus = 256;
+    e->waves = 4; e->groups = 1; e->tile_trees = 16; e->spec = 0; e->n_cus = 256;
     (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
 #define CK(x) do { int _r = (x); if (_r != AZG_OK) { g_create_err = e->err; azg_engine_destroy(e); return _r; } } while (0)
 #define HK(call) do { hipError_t _rc = (call); if (_rc != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_rc); azg_engine_destroy(e); return AZG_E_DEVICE; } } while (0)
@@ -856,7 +857,7 @@ int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1;
 // diagnostic: the form the last search ran in (engine_host.h: kernel_form)
 int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
-// head, waves, tree groups, trees per group; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
+// head, waves, tree groups, trees per group, compile-time specialisation; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
 // the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
@@ -865,7 +866,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
     int w = 0;
     switch (e->kernel_form) {
-        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees); break;
+        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees, e->spec); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2:
             w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb);

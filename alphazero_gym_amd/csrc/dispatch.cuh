@@ -12,9 +12,9 @@
 
 // One kernel variant: checks that its LDS plan fits the 160 KB of a CU (static + dynamic), then launches.
 // Returns hipErrorInvalidConfiguration (nothing launched) when it does not fit.
-template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16>
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16, int SPEC = 0>
 static hipError_t launch_g(azg_engine* e) {
-    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG, NT>;
+    auto kern = search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG, NT, SPEC>;
     static std::atomic<int> static_lds_cache{-1};   // per kernel variant; engines of several host threads may race to fill it
     int static_lds = static_lds_cache.load(std::memory_order_relaxed);
     if (static_lds < 0) {
@@ -44,16 +44,25 @@ static hipError_t launch_g(azg_engine* e) {
     dim3 grid((e->cfg.n_trees + tpw - 1) / tpw), block(64 * NW);
     e->tree_lds = TLDS;
     e->dyn_lds = L.total;
-    e->waves = NW; e->groups = NG; e->tile_trees = NT;
+    e->waves = NW; e->groups = NG; e->tile_trees = NT; e->spec = SPEC;
     e->kernel_form = 0;
     hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
     return hipGetLastError();
 }
 
+// Kernels specialised at compile time for the common parameter set (tree_phases.cuh: Spec<1> -- no epsilon-greedy selection,
+// lowest-index ties, and in the discrete family CartPole's two actions) exist for the shapes the BASELINE configurations and their
+// neighbours run on: one register-resident hidden->hidden layer, full tiles, trees in LDS with 8-bit ids.  Everything else, and
+// every engine whose parameters differ, runs the general kernels (AZG_NO_SPEC=1 forces them: tests).
 template <int ENV, int HP, int NREG, int TLDS, int NW, int NG, int NT = 16>
 static hipError_t launch_t(azg_engine* e) {
     if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4 && NT == 16) {
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
+    }
+    if constexpr (NREG == 1 && TLDS == TS_LDS8 && NT == 16) {
+        const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST &&
+                            (ENV != AZG_ENV_CARTPOLE || (e->cfg.env_id == AZG_ENV_CARTPOLE && e->cfg.num_actions == 2));
+        if (common && !e->opt.no_spec) return launch_g<ENV, HP, NREG, TLDS, false, NW, NG, NT, 1>(e);
     }
     return launch_g<ENV, HP, NREG, TLDS, false, NW, NG, NT>(e);
 }

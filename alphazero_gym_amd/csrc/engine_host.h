@@ -17,6 +17,7 @@ struct EngineOptions {
     int waves;                 // AZG_WAVES=4|8 (0: automatic)
     int groups;                // AZG_GROUPS=1|2 (0: automatic)
     int trace_cap;             // AZG_TRACE_CAP=n: traces a discrete tree may run per simulation step (0: automatic)
+    int no_spec;               // AZG_NO_SPEC=1: the general kernels where a compile-time specialised one exists (dispatch.cuh)
     int tile_trees;            // AZG_TILE_TREES=16|8: trees per 16-column MFMA tile of the small-network kernels (0: automatic)
     int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
     // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
@@ -50,6 +51,7 @@ struct azg_engine {
     int tree_lds;            // tree storage of the last launch: TS_GLOBAL, TS_LDS8, TS_LDS9 (records.h)
     int waves, groups, n_cus; // waves / tree groups per workgroup of the last launch; compute units of the device
     int tile_trees;          // trees per group (= per 16-column MFMA tile) of the last launch: 16, or 8 / 4 (half-filled tiles)
+    int spec;                // the last launch ran a compile-time specialised kernel (search_kernel's SPEC argument)
     size_t dyn_lds;          // dynamic LDS bytes per workgroup
     float ls_min, ls_max;
     hipStream_t stream;

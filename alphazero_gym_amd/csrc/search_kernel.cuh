@@ -41,7 +41,8 @@ __host__ __device__ inline LdsLayout lds_layout(int tab_n, int n_sims, int HP, i
 // activation buffers a kernel variant needs: one when a single register-resident hidden layer reads what layer 0 wrote
 __host__ __device__ constexpr int act_buffers(int NREG) { return NREG == 1 ? 1 : 2; }
 
-template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16>
+// SPEC: compile-time knowledge about run-time parameters (tree_phases.cuh: Spec<>; 0 = the general code)
+template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16, int SPEC = 0>
 __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParams P) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     static_assert(NT == 16 || (NG == 1 && NW == 4 && (NT == 8 || NT == 4)), "half-filled tiles: one group, four waves");
@@ -199,19 +200,19 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             // the path's rewards and cumulative returns (the descent did not fetch them: tree_phase_b<..., FETCH = false>)
             st.pr = 0.0; st.pW = 0.0;
             if (cx.live && (MULTI ? my_sim : sim) >= 0 && st.my_depth >= 1) {
-                st.pr = CONT ? cx.cold[st.pid].r : discrete_env_reward(P.env_id);
+                st.pr = CONT ? cx.cold[st.pid].r : discrete_env_reward(Spec<SPEC>::env(P));
                 st.pW = cx.edge_W[st.pid];
             }
         }
         if constexpr (!MULTI) {
             // ================= tree phase A: finish the evaluated leaf, back up =================
-            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
+            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
             if (sim == P.n_sims - 1) break;
             __threadfence_block();
             STAMP(t_d);
             // ================= tree phase B: next trace: select down, step the env, expand =================
             st.need_eval = false;
-            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
             __threadfence_block();
             STAMP(t_e);
             STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             int k = 0;
             while (run) {
                 STAMP(t_c2);
-                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
+                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
                 __threadfence_block();
                 STAMP(t_d);
                 st.need_eval = false;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
                     run = false;
                 } else {
                     my_sim += 1;
-                    tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+                    tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
                     __threadfence_block();
                     k += 1;
                     if (st.need_eval || k >= P.trace_cap) run = false;

@@ -23,6 +23,18 @@ struct TreeState {
     bool repeat;          // the pending trace is the previous one again: same path, same terminal leaf (set by tree_phase_b)
 };
 
+// Compile-time knowledge about run-time parameters.  SPEC = 1 (chosen by dispatch.cuh when it holds, for the kernel shapes the BASELINE
+// configurations run on; SPEC = 0 is the general code, same results): no epsilon-greedy selection, lowest-index ties, and -- the
+// discrete family -- CartPole with its two actions.  Every test on those parameters then folds away: no scalar compare / branch /
+// exec-mask bookkeeping around paths that are never taken, fewer values kept live in scalar registers.
+template <int SPEC> struct Spec {
+    static __device__ __forceinline__ bool eps0(const KParams& P) { return SPEC ? true : P.epsilon == 0.0; }
+    static __device__ __forceinline__ bool tie_random(const KParams& P) { return SPEC ? false : P.tie_random != 0; }
+    static __device__ __forceinline__ bool plain(const KParams& P) { return SPEC ? true : (P.epsilon == 0.0 && !P.tie_random); }
+    static __device__ __forceinline__ int A(const KParams& P) { return SPEC ? 2 : P.A; }                          // (discrete family)
+    static __device__ __forceinline__ int env(const KParams& P) { return SPEC ? (int)AZG_ENV_CARTPOLE : P.env_id; }   // (discrete family)
+};
+
 // ---- the cached selection of a node ("best"): the child the next descent through the node will take.
 // The reference scores a node's children when a trace comes by (selectionUCT).  Between two visits of a node nothing its
 // scores depend on changes -- its own count and its children's counts / Q move only when a trace passes through it, and the
@@ -52,7 +64,7 @@ template <bool CONT> __device__ __forceinline__ void set_best(RecL* r, const Rec
 
 // selectionUCT's scores and arg-max for node p (record hp, K = hp.n_child >= 1 children): the chosen child's record, the same in
 // all 16 lanes of the tree.  pick >= 0: that child index instead of the arg-max (epsilon-greedy).
-template <int ENV, int TLDS, typename Rec>
+template <int ENV, int TLDS, typename Rec, int SPEC = 0>
 __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TLDS>& ts, int p, const Rec& hp, int sub, const double* s_sqrt,
                                             int pick, unsigned gtree = 0u) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
@@ -79,10 +91,10 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
             float pc = ts.prior[c] * P.c_uct_f;   // float32 product (NumPy >= 2 promotion)
             U = h.Q + (double)pc * ratio;
         }
-        if (pick >= 0) win_c = __shfl(c, pick, 16);
+        if (!SPEC && pick >= 0) win_c = __shfl(c, pick, 16);
         else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
         else win_c = argmax16_payload(U, valid, sub, c);
-        if (P.tie_random && pick < 0) {
+        if (Spec<SPEC>::tie_random(P) && pick < 0) {
             // helpers.argmax (helpers.py:46-52): uniform among the children that hold the maximum.  The draw is keyed by the node
             // and its visit count: between two visits of a node nothing its scores depend on changes.
             const double m = rowmax16(U, valid);
@@ -129,12 +141,12 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
 }
 
 // Re-take the selection of node p after its statistics changed and store it with the node (lane 0 of the tree writes).
-template <int ENV, int TLDS>
+template <int ENV, int TLDS, int SPEC = 0>
 __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<TLDS>& ts, int p, int sub, const double* s_sqrt) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     typedef typename TreeStore<TLDS>::Rec Rec;
     const Rec hp = ts.hot[p];
-    const int b = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, -1);
+    const int b = select_child<ENV, TLDS, Rec, SPEC>(P, ts, p, hp, sub, s_sqrt, -1);
     if (sub == 0) set_best<CONT>(&ts.hot[p], hp, b);
 }
 
@@ -207,7 +219,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 // action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase
 // for the tree's group of 16 (PSTR entries per chunk), tl = the tree's column in that group.
 // RESUME (discrete mode, cached selections): also work out where the next descent leaves this trace's path (st.resume).
-template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false>
+template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false, int SPEC = 0>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
                                              const float* bhead, const double* s_sqrt STAMP_PARAM_OPT) {
@@ -256,7 +268,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
             }
         } else {
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
-            const int A = P.A;
+            const int A = Spec<SPEC>::A(P);
             // (logits 1 .. 3 come with out4; further actions, should an environment have them, through head_output)
             // lane a < A works on action a: its logit, its exp; the maximum and the sum are taken in action order (the sum as
             // ((0 + e_0) + e_1) + ..., the reference's order) from the lanes' values
@@ -292,7 +304,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 ts.hot[st.leaf].n_child = (decltype(ts.hot[st.leaf].n_child))A;
                 ts.hot[st.leaf].first = (decltype(ts.hot[st.leaf].first))k0;
             }
-            if (P.epsilon == 0.0 && !P.tie_random) {
+            if (Spec<SPEC>::plain(P)) {
                 // the new node's own selection (refresh_best): its edges all start at Q = V with no visits, so its scores
                 // are V + (prior_a * c_uct as float32) * (sqrt(n + 1) / 1) -- a division by one is exact
                 if (A == 2) {
@@ -308,7 +320,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     if (sub == 0) set_best<false>(&ts.hot[st.leaf], make_edge<Rec>(0.0, 0), U >= o ? 0 : 1);   // (index relative to first)
                 } else {
                     if (!TLDS) __threadfence_block();
-                    refresh_best<ENV, TLDS>(P, ts, st.leaf, sub, s_sqrt);
+                    refresh_best<ENV, TLDS, SPEC>(P, ts, st.leaf, sub, s_sqrt);
                 }
             }
         }
@@ -317,12 +329,12 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     STAMP_A_ADD(4, ta0, ta1);   // finish leaf
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
-        const bool keep = !CONT && P.epsilon == 0.0 && !P.tie_random;   // (cached selections: discrete mode, see rec_best)
+        const bool keep = !CONT && Spec<SPEC>::plain(P);   // (cached selections: discrete mode, see rec_best)
         Rec myrec;
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
-                                [&](int pn) { if (keep) refresh_best<ENV, TLDS>(P, ts, pn, sub, s_sqrt); }, myrec, st.chainR,
+                                [&](int pn) { if (keep) refresh_best<ENV, TLDS, SPEC>(P, ts, pn, sub, s_sqrt); }, myrec, st.chainR,
                                 RESUME && !CONT && st.repeat,    // (only the kernels that resume descents set st.repeat)
-                                CONT ? 0.0 : discrete_env_reward(P.env_id));
+                                CONT ? 0.0 : discrete_env_reward(Spec<SPEC>::env(P)));
         STAMP_A(ta2);
         STAMP_A_ADD(5, ta1, ta2);   // backup (return chain, record updates)
         if constexpr (!CONT) {
@@ -331,7 +343,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 // (anything deeper than 16 levels was refreshed by backup_from through the callback above)
                 const int D = st.path_D, lo = D > 15 ? D - 15 : 0;
                 if (!TLDS) __threadfence_block();
-                if (P.A == 2) {
+                if (Spec<SPEC>::A(P) == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
                     const bool mine = st.my_depth >= lo && st.my_depth < D;
                     const int win = refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, mine, s_sqrt, myrec);
@@ -346,7 +358,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                         st.resume = D < 16 ? (row ? __builtin_ctz(row) : D) : 0;
                     }
                 } else {
-                    for (int d = D - 1; d >= lo; --d) refresh_best<ENV, TLDS>(P, ts, __shfl(st.pid, d & 15, 16), sub, s_sqrt);
+                    for (int d = D - 1; d >= lo; --d) refresh_best<ENV, TLDS, SPEC>(P, ts, __shfl(st.pid, d & 15, 16), sub, s_sqrt);
                 }
             }
         }
@@ -360,7 +372,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 // FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
 // RESUME (discrete mode, cached selections): the descent starts where the last trace's path is left (st.resume, set by
 // tree_phase_a<..., RESUME = true>) instead of at the root; the path slots above that depth are still in the lanes.
-template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false>
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM) {
@@ -376,7 +388,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     bool resumed = false;
     st.repeat = false;
     if constexpr (RESUME && !CONT) {
-        if (P.epsilon == 0.0 && !P.tie_random && P.A == 2 && st.resume > 0) {
+        if (Spec<SPEC>::plain(P) && Spec<SPEC>::A(P) == 2 && st.resume > 0) {
             // same path as a descent from the root down to depth `resume` (tree_phase_a): go on from that node
             resumed = true;
             p = __shfl(st.pid, st.resume, 16);
@@ -386,7 +398,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     }
     // discrete mode: every step of the env pays the same reward, and a path slot that survives from the last trace (depths 1 ..
     // resume) still holds its record's W as the last backup left it: only records that enter the path are fetched
-    const double r_step = CONT ? 0.0 : discrete_env_reward(P.env_id);
+    const double r_step = CONT ? 0.0 : discrete_env_reward(Spec<SPEC>::env(P));
     const bool keep_slot = !CONT && FETCH && resumed && st.my_depth >= 1;
     Rec hp = ts.hot[p];
     Cold cp;             // cold part of the current node, prefetched one level ahead
@@ -411,14 +423,14 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
             if (widen) break;
         }
-        if (CONT || P.epsilon != 0.0 || P.tie_random) {
+        if (CONT || !Spec<SPEC>::plain(P)) {
             // scored on the way down (continuous mode; epsilon-greedy selection, MCTS.epsilon_greedy mcts.py:190-195; random ties)
             int pick = -1;
-            if (P.epsilon != 0.0) {
+            if (!Spec<SPEC>::eps0(P)) {
                 azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
                 if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
             }
-            chosen = select_child<ENV, TLDS, Rec>(P, ts, p, hp, sub, s_sqrt, pick, gtree);
+            chosen = select_child<ENV, TLDS, Rec, SPEC>(P, ts, p, hp, sub, s_sqrt, pick, gtree);
         } else {
             chosen = rec_best<CONT>(hp);   // taken when the node's statistics last changed (refresh_best)
         }
@@ -499,12 +511,12 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         } else {
             if constexpr (TLDS != TS_GLOBAL) {
                 if (ts.state) {
-                    const int slot = P.A == 2 ? ((int)hp.first - 1) >> 1 : ((int)hp.first - 1) / P.A;
+                    const int slot = Spec<SPEC>::A(P) == 2 ? ((int)hp.first - 1) >> 1 : ((int)hp.first - 1) / P.A;
                     const double* sp = ts.state + 4 * slot;
                     cp.s[0] = sp[0]; cp.s[1] = sp[1]; cp.s[2] = sp[2]; cp.s[3] = sp[3];
                 }
             }
-            discrete_env_step(P.env_id, cp.s, chosen - (int)hp.first, ns, &r, &done);
+            discrete_env_step(Spec<SPEC>::env(P), cp.s, chosen - (int)hp.first, ns, &r, &done);
         }
         float obs[4];
         env_obs<ENV>(ns, obs, &sn);
@@ -522,7 +534,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
             if constexpr (!CONT && TLDS != TS_GLOBAL) {
                 if (ts.state && !done) {   // the next node to be evaluated in this tree: its edges will start at record nrec
-                    double* sp = ts.state + 4 * (P.A == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
+                    double* sp = ts.state + 4 * (Spec<SPEC>::A(P) == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sp[k] = ns[k];
                 }

@@ -287,7 +287,7 @@ def kernel_name(eng):
 
 
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md)
-B_KERNEL = "search_kernel<0, 128, 1, 1, false, 4, 1, 16>"   # what config B is expected to run as (the engine reports what it did run)
+B_KERNEL = "search_kernel<0, 128, 1, 1, false, 4, 1, 16, 1>"   # what config B is expected to run as (the engine reports what it did run)
 
 
 def tree_walk_bytes(dump, n_actions, n_sims):
@@ -609,7 +609,7 @@ def main():
         elif not args.no_extra:
             extra["configs"] = [
                 extra_config("C at 8192 trees per GPU (the batch shape of real self-play runs: two 16-tree groups per CU)", PENDULUM, 8192, 200, 3, HIDDEN, 2, "elu",
-                             "search_kernel<2, 256, 1, 1, false, 8, 2, 16>", FLOP_PER_SIM,
+                             "search_kernel<2, 256, 1, 1, false, 8, 2, 16, 1>", FLOP_PER_SIM,
                              "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
                              B_KERNEL, None,
@@ -655,7 +655,7 @@ def main():
                          "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": kname + " (template arguments: ENV 2 = Pendulum, HP = padded hidden width, NREG = hidden->hidden layers held in "
                                    "registers, tree storage 1 = LDS with 8-bit ids, mixture head, waves per workgroup -- eight, of which the first four walk the trees --, "
-                                   "tree groups per workgroup, trees per group)",
+                                   "tree groups per workgroup, trees per group, 1 = compiled for epsilon 0 / lowest-index ties (the general kernel gives the same trees))",
                          "kernel_ms": kmean, "kernel_ms_median": kmed,
                          "note": "one launch = one whole search; achieved = trees x sims x 134144 FLOP / mean launch time (HIP events on the "
                                  "engine stream); policy/value MLP in fp32 MFMA, tree statistics in fp64; traffic = HBM bytes per launch from "

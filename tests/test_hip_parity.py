@@ -58,6 +58,9 @@ def _kernel_form(e):
     return _native.lib().azg_debug_kernel_form(C.c_void_p(e._h.value))
 
 
+_last_kernel_name = {}
+
+
 def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0, forms=None):
     e = engine_cls(**kw)
     e.set_weights(desc, blob)
@@ -66,6 +69,11 @@ def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0, forms=None):
     out = (e.results(), e.dump_tree(), e.root_children(), e.root_eval())
     if forms is not None:
         forms.append(_kernel_form(e))
+        import ctypes as C
+        from alphazero_gym_amd import _native
+        buf = C.create_string_buffer(256)
+        _native.lib().azg_debug_kernel_name(C.c_void_p(e._h.value), buf, C.c_size_t(256))
+        _last_kernel_name["name"] = buf.value.decode()
     e.close()
     return out
 
@@ -156,7 +164,7 @@ def slope_roots(roots):
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[f"cfg{i}" for i in range(len(CONFIGS))])
 @pytest.mark.parametrize("variant", ["default", "stream_weights", "global_tree", "persistent", "launches", "waves8", "waves4", "groups2",
-                                     "trace_cap1", "trace_cap64", "tile16"])
+                                     "trace_cap1", "trace_cap64", "tile16", "no_spec"])
 def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     """Seeded batches (ragged: not a multiple of the 16-tree workgroup) -- every record of every tree must be identical.
     Variants force the other code paths: weights streamed from L2 instead of registers, trees in global memory
@@ -181,6 +189,12 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
         if mode != 0 or max(hidden) > 256:
             pytest.skip("several traces per step: the discrete persistent search kernels")
         monkeypatch.setenv("AZG_TRACE_CAP", variant[len("trace_cap"):])
+    if variant == "no_spec":
+        # register-resident one-layer networks with common parameters run kernels specialised at compile time (dispatch.cuh: SPEC);
+        # this variant forces the general kernels on the same inputs
+        if len(hidden) != 2 or max(hidden) > 256 or ln or ncomp or extra.get("epsilon", 0.0) != 0.0 or n_sims > 126 or env == 3:
+            pytest.skip("no compile-time specialised kernel exists for this configuration")
+        monkeypatch.setenv("AZG_NO_SPEC", "1")
     if variant == "tile16":
         if max(hidden) > 128 or len(hidden) != 2 or ln or ncomp:
             pytest.skip("half-filled tiles exist for register-resident networks up to 128 wide")
@@ -218,6 +232,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=3, forms=forms)
     b = _run(O.OracleEngine, kw, desc, blob, roots, carry, sidx=3)
     _assert_same(a, b)
+    if variant in ("default", "no_spec") and forms == [0]:
+        spec = _last_kernel_name.get("name", "").rstrip(">").endswith(", 1")
+        if variant == "no_spec":
+            assert not spec, _last_kernel_name
     if env == 4:   # the point of these configurations: terminal nodes, and traces that ended in an existing one (no new record)
         assert ((a[1]["node_flags"] & 2) != 0).any(1).sum() >= B // 3 and (a[1]["n_records"] < n_sims + 1).sum() >= B // 3
 

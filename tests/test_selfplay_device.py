@@ -142,7 +142,8 @@ def _t7_engine(cls, case, **over):
     kw.update(over)
     e.selfplay_begin(**kw)
     if "first_roots" in case:   # (the T7 case's games start their first episode here instead of at the engine's reset state)
-        e.upload_roots(np.asarray(case["first_roots"], np.float64))
+        fr = np.asarray(case["first_roots"], np.float64)
+        e.upload_roots(fr[np.arange(case["n_games"]) % len(fr)])   # (larger batches of the same case: the roots repeat)
     return e
 
 
