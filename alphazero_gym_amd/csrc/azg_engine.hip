@@ -869,7 +869,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
         case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees, e->spec); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2:
-            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb);
+            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb, e->spec);
             break;
         default: w = snprintf(buf, n, "(no search yet)");
     }

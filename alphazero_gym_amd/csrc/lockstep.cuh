@@ -250,7 +250,11 @@ struct TileMem {
 // One output tile of a hidden->hidden layer: TG tree groups (from g0) x UT unit tiles (slice us), by one 256-thread workgroup.
 // KC_: k-blocks per staged chunk (LS_KC by default; the team kernel's three- and four-workgroups-per-CU forms use shorter chunks so
 // that their stages fit the CU's LDS side by side).
-template <int HP, bool LAST, int TG, int UT, bool SC1, int KC_ = LS_KC>
+// DBG (tools/probes/tile8 only; 0 in the product): 1 no global loads in the loop, 2 no staging stores / barriers, 4 no LDS operand reads
+// (Round 5 measured requesting chunk 0's weights BEFORE the team kernel's wait for the layer's input, so that their L2 round trip runs
+// under the wait: 13.38 against 13.23 ms per search at 1024 trees on one box, 24.17 against 24.25 ms at 2048 -- the registers that hold
+// the requested weights through the wait cost more than the round trip; not kept.)
+template <int HP, bool LAST, int TG, int UT, bool SC1, int KC_ = LS_KC, int DBG = 0>
 __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_ab, bool wt = true) {
     static_assert(!LAST || UT == 4, "a head chunk is 4 tiles");
     static_assert(TG == 4 || TG == 2, "4 waves: one or two per tree group");
@@ -324,7 +328,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
         for (int i = 0; i < WT; ++i) a[i] = sA[(i * KC) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
-            if (s + 1 < KC) {
+            if (s + 1 < KC && !(DBG & 4)) {
                 bn = sB[(s + 1) * 64 + lane];
 #pragma unroll
                 for (int i = 0; i < WT; ++i) an[i] = sA[(i * KC + s + 1) * 64 + lane];
@@ -339,20 +343,20 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
                     if (q >= SLOT0 && (q - SLOT0) % SLOTD == 0 && (q - SLOT0) / SLOTD < NL) {
                         const int j = (q - SLOT0) / SLOTD;
                         __builtin_amdgcn_sched_barrier(0);
-                        if (has1) store_one((c + 1) & 1, j);
-                        if (has2) load_one(c + 2, j);
+                        if (has1 && !(DBG & 2)) store_one((c + 1) & 1, j);
+                        if (has2 && !(DBG & 1)) load_one(c + 2, j);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            if (s + 1 < KC) {
+            if (s + 1 < KC && !(DBG & 4)) {
                 b = bn;
 #pragma unroll
                 for (int i = 0; i < WT; ++i) a[i] = an[i];
             }
         }
         if (LS_PIPE == 1 && has1) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
-        __syncthreads();
+        if (!(DBG & 2)) __syncthreads();
     };
     static_assert(NCHUNK >= 2, "the staging pipeline is written for at least two chunks");
 #pragma unroll 1

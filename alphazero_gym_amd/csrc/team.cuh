@@ -105,7 +105,8 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
 // KC: k-blocks per staged chunk of the tile routine; MINB: workgroups that have to fit a CU side by side (2: the default form,
 // 1024 trees at HP = 1024; 3 and 4 (shorter chunks: smaller stages, fewer registers): larger batches -- while one workgroup of a
 // CU waits at a hand-off or walks its trees, the others keep the matrix pipe busy).
-template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2>
+// SPEC: compile-time knowledge about run-time parameters for the tree phases (tree_phases.cuh: Spec<>; 0 = the general code).
+template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2, int SPEC = 0>
 __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
     constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
     constexpr int NU = HP / 64, NCH = HP / 64;
@@ -249,11 +250,11 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (the tree phases' own stamps: discarded here)
 #endif
         __builtin_amdgcn_s_setprio(3);   // the walking wave ahead of the other workgroups' MFMA waves on its SIMD (-0.7 % per search)
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt);
         st.need_eval = false;
         if (k < P.n_sims) {
             __threadfence_block();
-            if (live) tree_phase_b<ENV, TLDS, GMM, TPW>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
+            if (live) tree_phase_b<ENV, TLDS, GMM, TPW, int, true, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
         }
         __builtin_amdgcn_s_setprio(0);   // (after the tree phases on every path, the last step's included)
         if (k < P.n_sims) {

@@ -9,7 +9,7 @@
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
 // wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
 // otherwise it takes whatever the occupancy query allows (up to 6).
-template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB>
+template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0>
 static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     constexpr int NU = HP / 64, TPW = 32 / NU;
     constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
@@ -17,7 +17,7 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
     const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
     if ((lds + 1024) * MINB > 160 * 1024) return hipErrorNotReady;
-    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB>;
+    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB, SPEC>;
     // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel)
     static std::atomic<int> per_cu_caches[AZG_MAX_DEVICES];
     static std::atomic<size_t> lds_caches[AZG_MAX_DEVICES];
@@ -49,7 +49,7 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     e->kernel_form = 2;
     e->tree_lds = TLDS;
     e->dyn_lds = lds;
-    e->team_kc = KC; e->team_minb = MINB;
+    e->team_kc = KC; e->team_minb = MINB; e->spec = SPEC;
     return hipGetLastError();
 }
 
@@ -58,7 +58,15 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
 template <int ENV, int HP, bool GMM, int TLDS>
 static hipError_t team_launch(azg_engine* e) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
-    hipError_t rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, WIDE && e->opt.team_wide);
+    hipError_t rc;
+    // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
+    const bool common = WIDE && e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && !e->opt.no_spec;
+    if constexpr (WIDE) {
+        if (common) rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, e->opt.team_wide);
+        else rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, e->opt.team_wide);
+    } else {
+        rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false);
+    }
     if constexpr (WIDE) {
         if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);
         if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 4>(e, false);
