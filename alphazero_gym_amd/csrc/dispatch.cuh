@@ -60,8 +60,11 @@ static hipError_t launch_t(azg_engine* e) {
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
     }
     if constexpr (NREG == 1 && TLDS == TS_LDS8 && NT == 16) {
+        // (+ Pendulum-v1 in the Pendulum family; + no carried root count beyond the sqrt table in the discrete family)
         const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST &&
-                            (ENV != AZG_ENV_CARTPOLE || (e->cfg.env_id == AZG_ENV_CARTPOLE && e->cfg.num_actions == 2));
+                            (ENV != AZG_ENV_PENDULUM_V1 || e->cfg.env_id == AZG_ENV_PENDULUM_V1) &&
+                            (ENV != AZG_ENV_CARTPOLE || (e->cfg.env_id == AZG_ENV_CARTPOLE && e->cfg.num_actions == 2 &&
+                                                         (long)e->carry_max + e->cfg.n_sims + 2 <= (long)e->tab_n));
         if (common && !e->opt.no_spec) return launch_g<ENV, HP, NREG, TLDS, false, NW, NG, NT, 1>(e);
     }
     return launch_g<ENV, HP, NREG, TLDS, false, NW, NG, NT>(e);

@@ -60,7 +60,7 @@ static hipError_t team_launch(azg_engine* e) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
     hipError_t rc;
     // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
-    const bool common = WIDE && e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && !e->opt.no_spec;
+    const bool common = WIDE && e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
     if constexpr (WIDE) {
         if (common) rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, e->opt.team_wide);
         else rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, e->opt.team_wide);

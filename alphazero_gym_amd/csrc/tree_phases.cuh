@@ -24,8 +24,8 @@ struct TreeState {
 };
 
 // Compile-time knowledge about run-time parameters.  SPEC = 1 (chosen by dispatch.cuh when it holds, for the kernel shapes the BASELINE
-// configurations run on; SPEC = 0 is the general code, same results): no epsilon-greedy selection, lowest-index ties, and -- the
-// discrete family -- CartPole with its two actions.  Every test on those parameters then folds away: no scalar compare / branch /
+// configurations run on; SPEC = 0 is the general code, same results): no epsilon-greedy selection, lowest-index ties; the discrete
+// family: CartPole with its two actions and no carried root count beyond the sqrt table; the Pendulum family: Pendulum-v1.  Every test on those parameters then folds away: no scalar compare / branch /
 // exec-mask bookkeeping around paths that are never taken, fewer values kept live in scalar registers.
 template <int SPEC> struct Spec {
     static __device__ __forceinline__ bool eps0(const KParams& P) { return SPEC ? true : P.epsilon == 0.0; }
@@ -33,6 +33,9 @@ template <int SPEC> struct Spec {
     static __device__ __forceinline__ bool plain(const KParams& P) { return SPEC ? true : (P.epsilon == 0.0 && !P.tie_random); }
     static __device__ __forceinline__ int A(const KParams& P) { return SPEC ? 2 : P.A; }                          // (discrete family)
     static __device__ __forceinline__ int env(const KParams& P) { return SPEC ? (int)AZG_ENV_CARTPOLE : P.env_id; }   // (discrete family)
+    static __device__ __forceinline__ int v1(const KParams& P) { return SPEC ? 1 : P.v1; }                         // (Pendulum family: Pendulum-v1)
+    // every node count the search can meet lies inside the host-built sqrt(n + 1) table (no carried root count beyond it)
+    static __device__ __forceinline__ bool in_table(const KParams& P, int n) { return SPEC ? true : n < P.tab_n; }
 };
 
 // ---- the cached selection of a node ("best"): the child the next descent through the node will take.
@@ -72,7 +75,7 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
     // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
     // carry a count beyond the table, then the correctly rounded square root is computed in place
     double sq;
-    if (CONT || (int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
+    if (CONT || Spec<SPEC>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
     int win_c = 0;
     if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
@@ -155,13 +158,13 @@ __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<T
 // cross-lane traffic at all.  `mine`: the lane's slot holds a node of this path above the leaf.
 // hp: the lane's own record as backup_path left it (no second read; lanes without a slot hold a zero record, whose "children"
 // are records 0 and 1: valid addresses, results unused).
-template <int ENV, int TLDS>
+template <int ENV, int TLDS, int SPEC = 0>
 __device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const TreeStore<TLDS>& ts, int pid, bool mine, const double* s_sqrt,
                                                      const typename TreeStore<TLDS>::Rec& hp) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int p = mine ? pid : 0;
     double sq;
-    if ((int)hp.node_n < P.tab_n) sq = s_sqrt[hp.node_n];
+    if (Spec<SPEC>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
     const int c0 = (int)hp.first;
     const Rec h0 = ts.hot[c0], h1 = ts.hot[c0 + 1];
@@ -310,7 +313,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 if (A == 2) {
                     const int nn = (int)ts.hot[st.leaf].node_n;   // 0, or the carried count of a reused root
                     double sq;
-                    if (nn < P.tab_n) sq = s_sqrt[nn];
+                    if (Spec<SPEC>::in_table(P, nn)) sq = s_sqrt[nn];
                     else sq = __builtin_sqrt((double)(nn + 1));
                     float prior_s = 0.0f;
                     if (sub < A) prior_s = e_mine / sum;
@@ -346,7 +349,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 if (Spec<SPEC>::A(P) == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
                     const bool mine = st.my_depth >= lo && st.my_depth < D;
-                    const int win = refresh_best_own_slot<ENV, TLDS>(P, ts, st.pid, mine, s_sqrt, myrec);
+                    const int win = refresh_best_own_slot<ENV, TLDS, SPEC>(P, ts, st.pid, mine, s_sqrt, myrec);
                     if constexpr (RESUME) {
                         // The next trace follows the stored selections from the root: it walks this trace's path for as long as every
                         // node's (re-taken) selection is still the path's next record, i.e. down to the shallowest node whose
@@ -506,7 +509,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (CONT) {
             if (!widen) cact = action[chosen];
             if constexpr (ENV == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(cp.s, cact, ns, &r, &done);
-            else pendulum_step(P.v1, cp.s, cp.s[2], cact, ns, &r, &done);
+            else pendulum_step(Spec<SPEC>::v1(P), cp.s, cp.s[2], cact, ns, &r, &done);
             r = r / P.reward_scale;   // mcts.py:687 (whatever the env: the reference divides every continuous reward by PENDULUM_R_SCALE)
         } else {
             if constexpr (TLDS != TS_GLOBAL) {

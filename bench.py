@@ -524,12 +524,18 @@ def main():
         flat = torch.from_numpy(blob.copy())
         d_flat = None if on_host else torch.from_numpy(blob.copy()).to(ring.device)
         verify = {"checked": 0, "snap": None, "gathers": 0}
+        # what each rank's host saw (ms): the all-gather (call to data usable), the weight broadcast + engine re-sync, a whole loop
+        # iteration (wait for the previous step + collectives + launching the next one); filled while `timing` is on
+        tlog = {"on": False, "gather_ms": [], "bcast_ms": [], "step_ms": []}
 
         def gather(block):
             """all-gather one block of K finished steps (K * B rows per rank), HBM to HBM"""
             rows = ring[block]
+            g0 = time.perf_counter()
             dist.all_gather_into_tensor(gathered, rows.cpu() if on_host else rows)
             torch.cuda.current_stream().synchronize()         # the block is free again before the steps that overwrite it are launched
+            if tlog["on"]:
+                tlog["gather_ms"].append((time.perf_counter() - g0) * 1e3)
             verify["gathers"] += 1
             if args.verify_gather:
                 mine = gathered[rank * K * B:(rank + 1) * K * B]
@@ -542,9 +548,11 @@ def main():
             writes comes from the engine's own account (azg_selfplay_ring: steps played since begin), not from the loop index:
             the FIFO ring of 2 K steps keeps turning across calls of this function."""
             for s in range(steps):
+                it0 = time.perf_counter()
                 eng.sync()                                        # the previous step finished (it ran while the host did the last gather)
                 total = eng.selfplay_ring()[2]                    # steps played so far = index of the step about to be launched
                 if collectives and s > 0 and s % args.bcast_every == 0:
+                    b0 = time.perf_counter()
                     if on_host:                                   # functional run over gloo: staged through the host
                         dist.broadcast(flat, src=0)
                         eng.set_weights(desc, flat.numpy())
@@ -552,6 +560,8 @@ def main():
                         dist.broadcast(d_flat, src=0)
                         torch.cuda.current_stream().synchronize()
                         eng.set_weights_device(desc, d_flat.data_ptr(), d_flat.numel())
+                    if tlog["on"]:
+                        tlog["bcast_ms"].append((time.perf_counter() - b0) * 1e3)
                 full = collectives and total > 0 and total % K == 0   # steps total - K .. total - 1 fill one block, all finished
                 if full and args.verify_gather:
                     # the rows those K steps wrote, found without the slot formula: the block that differs from the snapshot taken
@@ -564,11 +574,15 @@ def main():
                 eng.selfplay_step()                               # launches only: this step now runs on the engine's stream
                 if full:
                     gather((total // K - 1) % 2)                  # FIFO, capacity 2 K: step k lives in slot k % 2K, block (k / K) % 2
+                if tlog["on"]:
+                    tlog["step_ms"].append((time.perf_counter() - it0) * 1e3)
 
         run(args.warmup, True)
         barrier()
         t0 = time.perf_counter()
+        tlog["on"] = True
         run(args.steps, True)
+        tlog["on"] = False
         barrier()
         elapsed = time.perf_counter() - t0
         barrier()
@@ -587,10 +601,20 @@ def main():
         parallelism = f"{world} ranks x {B} games (games sharded by global id; RCCL all-gather + broadcast outside the search)"
         if args.backend != "nccl":
             parallelism += f" [functional run: backend {args.backend}, rows staged through the host]"
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if args.backend != "nccl" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if config_d:
+            # every rank's own mean of each host-side interval -> min / median / max over the ranks (a straggler, or a rank whose
+            # collectives take longer than the others', shows here and nowhere else in the line)
+            mine = torch.tensor([float(np.mean(tlog[k])) if tlog[k] else -1.0 for k in ("gather_ms", "bcast_ms", "step_ms")] +
+                                [float(len(tlog["gather_ms"])), float(len(tlog["bcast_ms"])), float(dist.get_world_size())],
+                                dtype=torch.float64, device="cpu" if args.backend != "nccl" else "cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = torch.stack(allr).cpu().numpy()
         if config_d:
             t = torch.tensor([plain], device="cpu" if args.backend != "nccl" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -603,8 +627,18 @@ def main():
         if config_d:
             extra["search_only"] = {"sims_per_s": sims / plain, "ms_per_step": plain / args.steps * 1e3,
                                     "note": "the same self-play loop without the all-gather and the weight broadcast"}
+            def spread(col):
+                v = per_rank[:, col]
+                v = v[v >= 0]
+                return None if v.size == 0 else {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max())}
             extra["collectives"] = {"backend": args.backend, "world_size": world, "gather_every": K, "gathers": verify["gathers"],
                                     "gathers_verified": verify["checked"],
+                                    "world_size_seen": sorted(set(int(x) for x in per_rank[:, 5])),   # dist.get_world_size() of every rank
+                                    "per_rank_ms": {"gather_ms": spread(0), "bcast_ms": spread(1), "step_ms": spread(2),
+                                                    "gathers_timed": int(per_rank[:, 3].min()), "bcasts_timed": int(per_rank[:, 4].min()),
+                                                    "note": "host-side means of every rank over the timed run, then min / median / max over the ranks: "
+                                                            "all-gather call until its rows are usable, weight broadcast + engine re-sync, one whole "
+                                                            "loop iteration (wait for the previous step, collectives, launch of the next step)"},
                                     "weight_sync": "host (gloo functional run)" if on_host else "device to device: RCCL broadcast into HBM + azg_set_weights_device"}
         elif not args.no_extra:
             extra["configs"] = [

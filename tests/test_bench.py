@@ -75,13 +75,16 @@ def test_gpus_must_match_world_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_multi_rank_loop_on_one_gpu(ranks):
     """`python bench.py --gpus N` spawns its own ranks; config D's step (self-play step, all-gather of the step's rows, weight
-    broadcast + engine re-sync) runs with gloo and every rank on GPU 0 (N = 2 and 4: four tree_id_base offsets, four-way gather).
-    The N > 1 line carries the CPU baseline and a note about the traffic figure."""
+    broadcast + engine re-sync) runs with gloo and every rank on GPU 0: N = 2, 4 and 8 -- eight tree_id_base offsets, eight engines
+    on one device, an eight-way gather, 256 games per rank (the shape of the driver's 8-GPU run has run once
+    before the driver tries it).  The N > 1 line carries the CPU baseline, a note about the traffic figure and
+    every rank's host-side timings of the collectives (min / median / max over the ranks) with the world size each rank saw."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--trees", "512",
+    trees = "256" if ranks == 8 else "512"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--trees", trees,
                         "--bcast-every", "2", "--backend", "gloo", "--same-device"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
@@ -91,6 +94,12 @@ def test_multi_rank_loop_on_one_gpu(ranks):
     assert "traffic_note" in out["roofline"]
     assert out["value"] > 0 and out["extra"]["search_only"]["sims_per_s"] >= out["value"] * 0.5
     assert "config D" in out["config"]["workload"]
+    c = out["extra"]["collectives"]
+    assert c["world_size"] == ranks and c["world_size_seen"] == [ranks]
+    pr = c["per_rank_ms"]
+    assert pr["gathers_timed"] >= 1 and pr["bcasts_timed"] >= 1
+    for k in ("gather_ms", "bcast_ms", "step_ms"):
+        assert 0 < pr[k]["min"] <= pr[k]["median"] <= pr[k]["max"], (k, pr[k])
 
 
 @pytest.mark.gpu
