@@ -132,8 +132,18 @@ struct LockStep {
 
 
 #ifdef AZG_STAMPS
+#ifdef AZG_STAMPS_ONLY_ENV   /* one stamp pair only -- around the env step + observation of tree phase B (slot 15) --, so that the build
+                                runs within a few per cent of the product's time (the full set of stamps costs the lean kernels 20 %) */
+#define STAMP(var)
+#define STAMP_ADD(slot, t0, t1)
+#define STAMP_ENV(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ENV_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#else
 #define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#define STAMP_ENV(var) STAMP(var)
+#define STAMP_ENV_ADD(slot, t0, t1) STAMP_ADD(slot, t0, t1)
+#endif
 #define STAMP_PARAM , unsigned long long* st_acc
 #define STAMP_ARG , st_acc
 #ifdef AZG_STAMPS_A   /* slots 4..6 = phase A's parts (finish leaf | backup | re-scoring) instead of the network's */
@@ -151,6 +161,8 @@ struct LockStep {
 #define STAMP_ARG
 #define STAMP(var)
 #define STAMP_ADD(slot, t0, t1)
+#define STAMP_ENV(var)
+#define STAMP_ENV_ADD(slot, t0, t1)
 #define STAMP_A(var)
 #define STAMP_A_ADD(slot, t0, t1)
 #define STAMP_M_ADD(slot, t0, t1)

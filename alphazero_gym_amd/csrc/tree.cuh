@@ -249,11 +249,21 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
         // needs nothing from the other lanes: every lane runs it by itself (two dependent float64 operations per level instead of
         // a DPP round trip) and keeps the value of its own slot -- the same operations in the same order as the travelling form
         double R = 0.0;
+        if (gamma == 1.0) {
+            // gamma * x is x itself, bit for bit, for gamma == 1 (the reference's default): one operation per level instead of two
+            R = (double)V;
 #pragma unroll 2
-        for (int d = 0; d < n0; ++d) {
-            const double gR = d == 0 ? gamma * (double)V : gamma * R;
-            R = r_uniform + gR;
-            if (sub == ((D - d) & 15)) myR = R;
+            for (int d = 0; d < n0; ++d) {
+                R = r_uniform + R;
+                if (sub == ((D - d) & 15)) myR = R;
+            }
+        } else {
+#pragma unroll 2
+            for (int d = 0; d < n0; ++d) {
+                const double gR = d == 0 ? gamma * (double)V : gamma * R;
+                R = r_uniform + gR;
+                if (sub == ((D - d) & 15)) myR = R;
+            }
         }
         Rv = R;            // (D >= 16: the return of the shallowest of the 16 levels, handed to backup_from)
         chainR = myR;

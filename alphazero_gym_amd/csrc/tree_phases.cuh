@@ -467,7 +467,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         STAMP_ADD(9, tl2, tl3);    // chosen record
         STAMP_ADD(10, tl3, tl4);   // path slot + cold prefetch issue
         STAMP_ADD(11, tl0, tl4);   // full level
-#ifdef AZG_STAMPS
+#if defined(AZG_STAMPS) && !defined(AZG_STAMPS_ONLY_ENV)
         st_acc[12] += 1;
 #endif
     }
@@ -501,7 +501,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
         }
         // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
-        STAMP(tw1);
+        STAMP_ENV(tw1);
         STAMP_ADD(14, tb1, tw1);   // widening (noise, policy parameters, tanh, edge record, child list)
         st.path_D += 1;
         double ns[S], r, sn;
@@ -523,8 +523,8 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         }
         float obs[4];
         env_obs<ENV>(ns, obs, &sn);
-        STAMP(tw2);
-        STAMP_ADD(15, tw1, tw2);   // env step + observation
+        STAMP_ENV(tw2);
+        STAMP_ENV_ADD(15, tw1, tw2);   // env step + observation
         if (sub == 0) {
             Cold c;
 #pragma unroll

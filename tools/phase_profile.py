@@ -8,9 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASE_A = "--phase-a" in sys.argv   # slots 4..6 = phase A's parts (libazgym_hip_stampa.so) instead of the network's
-if PHASE_A:
-    sys.argv.remove("--phase-a")
-os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc", "libazgym_hip_stampa.so" if PHASE_A else "libazgym_hip_stamp.so")
+ENV_ONLY = "--env-only" in sys.argv  # libazgym_hip_stampe.so: ONE stamp pair (env step + observation of phase B): runs close to the product's time
+for flag in ("--phase-a", "--env-only"):
+    if flag in sys.argv:
+        sys.argv.remove(flag)
+os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc",
+                                         "libazgym_hip_stampe.so" if ENV_ONLY else ("libazgym_hip_stampa.so" if PHASE_A else "libazgym_hip_stamp.so"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

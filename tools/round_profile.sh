@@ -2,7 +2,7 @@
 # GPU box: the round's evidence in one call -> gpurun_out/<tag>_*; copy what is to be judged into profiles/ afterwards
 # (tools/digest_profile.py <tag> <tag>; the phase profiles and config B's summary are copied as they are).
 # usage: bash tools/round_profile.sh <tag>     (build the stamped libraries first: make -C alphazero_gym_amd/csrc libazgym_hip_stamp.so libazgym_hip_stampa.so)
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -17,6 +17,23 @@ if [ -f alphazero_gym_amd/csrc/libazgym_hip_stampa.so ]; then
   python3 tools/phase_profile.py cartpole 4096 --phase-a > $OUT/${TAG}_phase_B_treeA.txt 2>&1
 fi
 python3 tools/team_profile.py 1024 > $OUT/${TAG}_team_profile.txt 2>&1
+# env step + observation of phase B with ONE stamp pair (a build that runs within a few per cent of the product): 8- and 4-wave kernels
+if [ -f alphazero_gym_amd/csrc/libazgym_hip_stampe.so ]; then
+  ( echo "== product library"; python3 tools/quick_times.py C B; AZG_WAVES=4 python3 tools/quick_times.py C
+    echo "== one stamp pair (env step + observation), 8 waves"; python3 tools/phase_profile.py pendulum 4096 --env-only
+    echo "== one stamp pair, 4 waves (AZG_WAVES=4)"; AZG_WAVES=4 python3 tools/phase_profile.py pendulum 4096 --env-only
+    echo "== one stamp pair, config B"; python3 tools/phase_profile.py cartpole 4096 --env-only ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_env_step_stamp.txt
+fi
+# the wide network's hidden-layer tiles by themselves (tools/probes/tile8/README.md)
+if [ -x tools/probes/tile8/tile8_probe ]; then
+  for d in 1 32; do echo "== activation blocks / $d"; tools/probes/tile8/tile8_probe 200 $d; done > $OUT/${TAG}_tile_probe.txt 2>&1
+fi
+# BASELINE shapes with the general kernels beside the compile-time specialised ones, same box
+( python3 tools/quick_times.py C B C8192 B8192 E E2048; AZG_NO_SPEC=1 python3 tools/quick_times.py C B C8192 B8192 ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_quick_times.txt
+# end-to-end learning on one GPU (examples/selfplay_train.py)
+python3 examples/selfplay_train.py --game CartPole-v0 --games 512 --n-rollouts 32 --iters 80 2>/dev/null | grep "^{" > $OUT/${TAG}_learning_cartpole.jsonl
+python3 examples/selfplay_train.py --game Pendulum-v1 --games 512 --n-rollouts 50 --iters 40 --steps-per-iter 200 --train-rows 16384 --batch-size 128 2>/dev/null | grep "^{" > $OUT/${TAG}_learning_pendulum.jsonl
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 # rocprofv3: kernel stats + PMC passes of the headline command, and of config B (with the HBM passes)
 bash tools/profile_bench.sh $TAG > $OUT/${TAG}_profile_bench.log 2>&1
 bash tools/profile_config_b.sh $TAG > $OUT/${TAG}_profile_b.log 2>&1
