@@ -279,7 +279,10 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
         if (j < NLA) ra[jj] = W[((size_t)(t0 + i) * S4 + c * KC) * 64 + r];
         else rb[jj] = in.load4(((size_t)(g0 + i) * S4 + c * KC) * 64 + r);
     };
+    f32x4 dbg_const = {1.0f, 2.0f, 3.0f, 4.0f};
+    if (DBG & 8) asm volatile("" : "+v"(dbg_const));
     auto store_one = [&](int st, int j) {
+        if (DBG & 8) { s_ab[st * STAGE + j * 256 + tid] = dbg_const; return; }
         if (j < NLA) s_ab[st * STAGE + j * 256 + tid] = ra[j];
         else s_ab[st * STAGE + ASZ + (j - NLA) * 256 + tid] = rb[j - NLA];
     };
@@ -363,6 +366,12 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     for (int c = 0; c < NCHUNK - 2; ++c) chunk(c, std::true_type{}, std::true_type{});
     chunk(NCHUNK - 2, std::true_type{}, std::false_type{});
     chunk(NCHUNK - 1, std::false_type{}, std::false_type{});
+    if (DBG & 8) {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+        for (int j = 0; j < NLB; ++j) asm volatile("" ::"v"(rb[j]));
+    }
     f32x4 h[WT];
 #pragma unroll
     for (int i = 0; i < WT; ++i) h[i] = act4<true>(P.act, acc[i]);

@@ -705,7 +705,7 @@ def _t3_scale_chunk(job):
 T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engine kwargs)   -- BASELINE configs C, B, E
     "c": (2, 1, [256, 256], "elu", 200, 4096, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
     "b": (0, 0, [128, 128], "relu", 100, 4096, dict(c_uct=1.5, gamma=1.0, num_actions=2)),
-    "e": (2, 1, [1024] * 4, "elu", 200, 128, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
+    "e": (2, 1, [1024] * 4, "elu", 200, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),
     # the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): 2-component mixture head on a 3x128 ELU
     # trunk with 25 rollouts; 2x128 ReLU with 8 rollouts and epsilon-greedy 0.1 (draws: the engine's, injected as `random`)
     "g": (2, 1, [128, 128, 128], "elu", 25, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5)),

@@ -1,7 +1,7 @@
 """Tier T3 at BASELINE scale (VERDICT r03 row g): visit-count parity with the reference run END TO END -- the reference's
 MCTSContinuous.search / MCTSDiscrete.search (alphazero/search/mcts.py:418-462, 656-702) with its REAL torch policies
 (alphazero/network/policies.py:340-352, 436-499) -- on the engine's own synthetic roots of configs C (all 4096 trees, 2x256 ELU,
-200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (128 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
+200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (512 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
 each -- of the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): the 2-component mixture head on a
 3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`);
 and 1024 trees of gym MountainCar-v0 (three actions) with the reference's DiscretePolicy; and 1024 trees of gym
@@ -41,7 +41,7 @@ LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims, network ou
     # the reference's DiagonalNormalPolicy (2x256 ELU, action bound 1), 120 rollouts, roots on the slope below the flag
     "h": (dict(env_id=4, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, action_bound=1.0, seed=34), 2, [256, 256], "elu", 120, 2, 0, 34),
 }
-N_TREES_ALL = 4096 + 4096 + 128 + 1024 + 1024 + 1024 + 1024
+N_TREES_ALL = 4096 + 4096 + 512 + 1024 + 1024 + 1024 + 1024
 
 
 def mcc_scale_roots(synthetic):

@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) report(name, 512.0 * iters * 3 * 2.0 * 32 * 64 * 1024, ms);
         };
+        run4(probe4<2, 8>, "   the same, loads issued but never waited for");
         run4(probe4<2, 1>, "   the same without global loads in the loop");
         run4(probe4<2, 3>, "   ... and without staging stores and barriers");
         run4(probe4<2, 7>, "   ... and without LDS operand reads (MFMAs only)");
