@@ -18,7 +18,7 @@ AZG_E_DEVICE = -3
 AZG_E_STATE = -4
 AZG_E_UNSUPPORTED = -5
 
-ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT = 0, 1, 2, 3, 4
+ENV_CARTPOLE, ENV_PENDULUM_V0, ENV_PENDULUM_V1, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_ACROBOT = 0, 1, 2, 3, 4, 5
 MODE_DISCRETE, MODE_CONTINUOUS = 0, 1
 VT = {"off_policy": 0, "on_policy": 1, "greedy": 2}
 TIE = {"first": 0, "random": 1}   # helpers.argmax on exactly equal scores: lowest index (parity) or a Philox-keyed uniform pick

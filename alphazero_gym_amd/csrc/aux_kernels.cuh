@@ -183,16 +183,18 @@ __global__ __launch_bounds__(16 * SP_TREES) void selfplay_kernel16(KParams P, Se
     if (sub != 0) return;
     double root[4] = {0.0, 0.0, 0.0, 0.0};
     for (int k = 0; k < S; ++k) root[k] = sp.roots[(size_t)tree * S + k];
-    float obs[4];
-    double sn;
-    // (the discrete family's observation is its state as float32: MountainCar's unused slots 2..3 are zero)
-    // (the MountainCars' observation is (position, velocity): the discrete family's state as float32 with S_obs = 2)
-    if (!cont || env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
-    for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
+    float obs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    double sn = 0.0;
+    // (the MountainCars' observation is (position, velocity): the discrete family's state as float32 with S_obs = 2; Acrobot: six)
+    if (!cont) discrete_env_obs(env_id, root, obs);
+    else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn);
+    else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    for (int k = 0; k < 8; ++k) if (k < S_obs) row[k] = obs[k];
     row[S_obs + 3 * K] = (float)(v_target == AZG_VT_ON_POLICY ? onp : qmax);
     double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
     int done;
-    if (!cont) discrete_env_step(env_id, root, pick, ns, &r, &done);
+    if (!cont && env_id == AZG_ENV_ACROBOT) azg_acrobot_step(root, pick, ns, &r, &done);
+    else if (!cont) discrete_env_step(env_id, root, pick, ns, &r, &done);
     else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(root, pact, ns, &r, &done);
     else pendulum_step(env_id == AZG_ENV_PENDULUM_V1, root, sn, pact, ns, &r, &done);
     double ret = sp.ret[tree] + r;
@@ -232,11 +234,12 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
     const bool staged = Kmax <= RK_MAX;
     if (staged) root_kids_load(P, tb, r0, cont, &s_kids[threadIdx.x]);
     const RootView rv{P, tb, r0, cont, &s_kids[threadIdx.x], staged};
-    float obs[4];
-    double sn;
-    // (the discrete family's observation is its state as float32: MountainCar's unused slots 2..3 are zero)
-    if (!cont || env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn); else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
-    for (int k = 0; k < S_obs; ++k) row[k] = obs[k];
+    float obs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    double sn = 0.0;
+    if (!cont) discrete_env_obs(env_id, root, obs);
+    else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) env_obs<AZG_ENV_CARTPOLE>(root, obs, &sn);
+    else env_obs<AZG_ENV_PENDULUM_V1>(root, obs, &sn);
+    for (int k = 0; k < 8; ++k) if (k < S_obs) row[k] = obs[k];
     double qmax = 0.0, onp = 0.0;
     long tot = 0;
     int cmax = 0, amax = 0;
@@ -307,7 +310,9 @@ __global__ __launch_bounds__(RK_THREADS) void selfplay_kernel(KParams P, SelfPla
     }
     double ns[4] = {0.0, 0.0, 0.0, 0.0}, r;
     int done;
-    if (!cont) {
+    if (!cont && env_id == AZG_ENV_ACROBOT) {
+        azg_acrobot_step(root, pick, ns, &r, &done);
+    } else if (!cont) {
         discrete_env_step(env_id, root, pick, ns, &r, &done);
     } else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) {
         mountaincar_cont_step(root, rv.act(pick), ns, &r, &done);

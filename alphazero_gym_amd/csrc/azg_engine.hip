@@ -116,6 +116,7 @@ static int env_digit(const char* name, int dflt) {
 
 static bool use_lockstep(const azg_engine* e) {
     if (e->opt.force_persistent) return false;
+    if (e->P.in8) return false;   // (more than four network inputs: the lock-step / team kernels' first layer takes one k-step only)
     return e->HP >= 512 && e->n_hidden >= 2 && !e->P.layernorm;
 }
 
@@ -212,14 +213,14 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     }
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(nullptr, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(nullptr, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_MOUNTAINCAR_CONT) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
-    const bool discrete_env = cfg->env_id == AZG_ENV_CARTPOLE || cfg->env_id == AZG_ENV_MOUNTAINCAR;
+    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_ACROBOT) return fail(nullptr, AZG_E_INVALID, "unknown env_id");
+    const bool discrete_env = cfg->env_id == AZG_ENV_CARTPOLE || cfg->env_id == AZG_ENV_MOUNTAINCAR || cfg->env_id == AZG_ENV_ACROBOT;
     if (cfg->mode == AZG_MODE_DISCRETE && !discrete_env)
-        return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole, MountainCar)");
+        return fail(nullptr, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole, MountainCar, Acrobot)");
     if (cfg->mode == AZG_MODE_CONTINUOUS && discrete_env)
         return fail(nullptr, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum, MountainCarContinuous)");
     if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != (cfg->env_id == AZG_ENV_CARTPOLE ? 2 : 3))
-        return fail(nullptr, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3)");
+        return fail(nullptr, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3, Acrobot 3)");
     if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(nullptr, AZG_E_INVALID, "unknown tie_break");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_E_DEVICE, "no HIP device available");
@@ -252,8 +253,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->stream = nullptr; e->ev0 = e->ev1 = nullptr;
     e->publish_always = env_digit("AZG_PUBLISH_TREES", 0) == 1; e->publish_once = 0; e->published = 0; e->redo_ok = 0;
     e->mlp_ready = 0; e->searched = 0; e->results_valid = 0; e->search_idx = 0; e->last_ms = 0.0f; e->sp_on = 0; e->ls_hp = 0;
-    e->S_env = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : 2;
-    e->S_obs = cfg->env_id == AZG_ENV_CARTPOLE ? 4 : ((cfg->env_id == AZG_ENV_MOUNTAINCAR || cfg->env_id == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3);
+    e->S_env = (cfg->env_id == AZG_ENV_CARTPOLE || cfg->env_id == AZG_ENV_ACROBOT) ? 4 : 2;
+    e->S_obs = cfg->env_id == AZG_ENV_ACROBOT ? 6 : (cfg->env_id == AZG_ENV_CARTPOLE ? 4 : ((cfg->env_id == AZG_ENV_MOUNTAINCAR || cfg->env_id == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3));
     const int ns = cfg->n_sims;
     std::vector<int> pw(ns + 2, 0);
     if (cfg->mode == AZG_MODE_CONTINUOUS) {
@@ -406,7 +407,8 @@ static void build_weight_map(const azg_mlp_desc* d, int HP, WeightMap& m) {
     // (, LayerNorm weight, bias), then value head, distribution head)
     std::vector<std::vector<idx_t>> Wd(d->n_hidden), bd(d->n_hidden), gd(d->n_hidden), ed(d->n_hidden);
     idx_t p = 1;
-    int kt = d->in_dim, kp = 4;
+    const int kp0 = d->in_dim > 4 ? 8 : 4;   // the first layer's input slots: one MFMA k-step, or two (five to eight inputs)
+    int kt = d->in_dim, kp = kp0;
     for (int l = 0; l < d->n_hidden; ++l) {
         const int h = d->hidden[l];
         Wd[l].assign((size_t)HP * kp, 0);
@@ -440,15 +442,17 @@ static void build_weight_map(const azg_mlp_desc* d, int HP, WeightMap& m) {
     st.clear();
     auto reserve = [&](size_t n) { size_t off = st.size(); st.resize(off + (n + 63) / 64 * 64, 0); return off; };
     m.oW0 = reserve((size_t)NT * 64); m.ob0 = reserve((size_t)NT * 64 * 4);
+    m.oW0b = reserve((size_t)NT * 64);        // inputs 4..7 (zeros for networks of at most four inputs)
     for (int t = 0; t < NT; ++t)
         for (int l = 0; l < 64; ++l) {
             const int row = 16 * t + (l & 15), g = l >> 4;
-            st[m.oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * 4 + g];
+            st[m.oW0 + (size_t)t * 64 + l] = Wd[0][(size_t)row * kp0 + g];
+            st[m.oW0b + (size_t)t * 64 + l] = kp0 == 8 ? Wd[0][(size_t)row * kp0 + 4 + g] : 0;
             for (int r = 0; r < 4; ++r) st[m.ob0 + ((size_t)t * 64 + l) * 4 + r] = bd[0][16 * t + 4 * g + r];
         }
     m.oW0u = reserve((size_t)HP * 4); m.ob0u = reserve((size_t)HP);
-    for (int u = 0; u < HP; ++u) {
-        for (int kk = 0; kk < 4; ++kk) st[m.oW0u + (size_t)u * 4 + kk] = Wd[0][(size_t)u * 4 + kk];
+    for (int u = 0; u < HP; ++u) {   // (the VALU form of the first layer, team kernel: networks of at most four inputs only)
+        for (int kk = 0; kk < 4; ++kk) st[m.oW0u + (size_t)u * 4 + kk] = Wd[0][(size_t)u * kp0 + kk];
         st[m.ob0u + u] = bd[0][u];
     }
     for (int l = 0; l < MAX_STREAM_LAYERS; ++l) { m.oWl[l] = m.obl[l] = m.olg[l] = m.olb[l] = 0; }
@@ -545,6 +549,8 @@ static int set_weights_impl(azg_engine* e, const azg_mlp_desc* d, const float* b
     e->P.W0u = (const f32x4*)(wb + m.oW0u);
     e->P.b0u = (const f32x4*)(wb + m.ob0u);
     e->P.W0 = wb + m.oW0;
+    e->P.W0b = wb + m.oW0b;
+    e->P.in8 = d->in_dim > 4 ? 1 : 0;
     e->P.b0 = (const f32x4*)(wb + m.ob0);
     for (int l = 0; l < MAX_STREAM_LAYERS; ++l) {
         const bool on = l + 1 < d->n_hidden;
@@ -606,6 +612,9 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
             if ((s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr))
                 return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         }
+    } else if (e->cfg.env_id == AZG_ENV_ACROBOT) {
+        for (int i = 0; i < B; ++i)
+            if (azg_acrobot_terminal(roots + (size_t)i * S)) return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
     } else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR || e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) {
         // (mcts.py:382-383, 599-600; the flag is at 0.5 in MountainCar-v0, at 0.45 in MountainCarContinuous-v0)
         const double goal = e->cfg.env_id == AZG_ENV_MOUNTAINCAR ? 0.5 : 0.45;
@@ -649,6 +658,7 @@ int azg_search_resident(azg_engine* e) {
     const bool cartpole = e->cfg.mode == AZG_MODE_DISCRETE;   // the discrete family's kernels (CartPole, MountainCar)
     const bool mcc = e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT;   // the continuous family whose episodes end (env.cuh: EnvFamily)
     if (lockstep) rc = cartpole ? azg_ls_dispatch_cartpole(e) : (mcc ? azg_ls_dispatch_mcc(e) : azg_ls_dispatch_pendulum(e));
+    else if (e->cfg.env_id == AZG_ENV_ACROBOT) rc = azg_dispatch_acrobot(e);
     else if (cartpole) rc = azg_dispatch_cartpole(e);
     else if (mcc) rc = azg_dispatch_mcc(e);
     else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
@@ -861,8 +871,8 @@ int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
 // the length written
 int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
     if (!e || !buf || n == 0) return AZG_E_INVALID;
-    // (ENV = 0: the discrete family, ENV = 2: both Pendulum versions, ENV = 4: MountainCarContinuous)
-    const int env = e->cfg.mode == AZG_MODE_DISCRETE ? 0 : (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT ? 4 : 2);
+    // (ENV = 0: the CartPole / MountainCar family, 5: Acrobot, 2: both Pendulum versions, 4: MountainCarContinuous)
+    const int env = e->cfg.mode == AZG_MODE_DISCRETE ? (e->cfg.env_id == AZG_ENV_ACROBOT ? 5 : 0) : (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT ? 4 : 2);
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
     int w = 0;
     switch (e->kernel_form) {

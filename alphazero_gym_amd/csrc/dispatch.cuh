@@ -27,7 +27,7 @@ static hipError_t launch_g(azg_engine* e) {
     // discrete LDS trees: the expanded nodes' env states go to LDS too when the CU has room for them -- and when that does not
     // cost a second resident workgroup: a batch with more workgroups than CUs runs two of them side by side on a CU if their LDS
     // allows it, which is worth far more (CartPole, 8192 trees, 2x128: 0.62 ms per search against 0.94 ms)
-    constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     LdsLayout L = lds_layout(e->tab_n, e->cfg.n_sims, HP, NG, act_buffers(NREG), e->R, CONT, TLDS, 1, NT);
     const long n_wg = (e->cfg.n_trees + NT * NG - 1) / (NT * NG);
     const size_t with_state = L.total + (size_t)static_lds;
@@ -56,10 +56,10 @@ static hipError_t launch_g(azg_engine* e) {
 // every engine whose parameters differ, runs the general kernels (AZG_NO_SPEC=1 forces them: tests).
 template <int ENV, int HP, int NREG, int TLDS, int NW, int NG, int NT = 16>
 static hipError_t launch_t(azg_engine* e) {
-    if constexpr (ENV != AZG_ENV_CARTPOLE && NW == 4 && NT == 16) {
+    if constexpr (EnvFamily<ENV>::CONT && NW == 4 && NT == 16) {
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
     }
-    if constexpr (NREG == 1 && TLDS == TS_LDS8 && NT == 16) {
+    if constexpr (NREG == 1 && TLDS == TS_LDS8 && NT == 16 && ENV != AZG_ENV_ACROBOT) {
         // (+ Pendulum-v1 in the Pendulum family; + no carried root count beyond the sqrt table in the discrete family)
         const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST &&
                             (ENV != AZG_ENV_PENDULUM_V1 || e->cfg.env_id == AZG_ENV_PENDULUM_V1) &&
@@ -90,7 +90,7 @@ static hipError_t launch(azg_engine* e) {
     if (e->opt.force_global_tree) ts = TS_GLOBAL;
     // (Continuous mode only.  The discrete family's 8-wave shapes were measured slower than its 4-wave ones -- CartPole, 8192 trees,
     // 2x256: 1.03 ms against 0.99 ms per search, and they were the only kernels of the family that spilled registers -- and are gone.)
-    if constexpr (HP == 256 && NREG == 1 && ENV != AZG_ENV_CARTPOLE) {
+    if constexpr (HP == 256 && NREG == 1 && EnvFamily<ENV>::CONT) {
         bool two = (e->cfg.n_trees + 15) / 16 > e->n_cus;
         if (e->opt.groups == 2) two = true;
         if (e->opt.groups == 1) two = false;

@@ -39,7 +39,7 @@ struct WeightMap {
     azg_mlp_desc desc;
     int HP = 0;
     std::vector<unsigned> src;   // per output float: 1 + index into the caller's blob, 0 = padding zero
-    size_t oW0, ob0, oW0u, ob0u, oWl[MAX_STREAM_LAYERS], obl[MAX_STREAM_LAYERS], oWh, obh, olg[MAX_STREAM_LAYERS], olb[MAX_STREAM_LAYERS];
+    size_t oW0, oW0b, ob0, oW0u, ob0u, oWl[MAX_STREAM_LAYERS], obl[MAX_STREAM_LAYERS], oWh, obh, olg[MAX_STREAM_LAYERS], olb[MAX_STREAM_LAYERS];
 };
 
 struct azg_engine {
@@ -104,6 +104,7 @@ struct azg_engine {
 hipError_t azg_dispatch_cartpole(azg_engine* e);
 hipError_t azg_dispatch_pendulum_small(azg_engine* e);   // hidden width (padded) <= 128
 hipError_t azg_dispatch_pendulum_large(azg_engine* e);   // 256 and wider
+hipError_t azg_dispatch_acrobot(azg_engine* e);          // Acrobot-v1 (discrete MCTS, six network inputs), all widths, one-launch kernels only
 hipError_t azg_dispatch_mcc(azg_engine* e);              // MountainCarContinuous (continuous MCTS with terminal nodes), all widths
 hipError_t azg_ls_dispatch_mcc(azg_engine* e);
 hipError_t azg_team_dispatch_mcc(azg_engine* e);

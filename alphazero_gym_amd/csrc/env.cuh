@@ -10,10 +10,14 @@
 //   AZG_ENV_MOUNTAINCAR_CONT  one continuous action, episodes END (MountainCarContinuous-v0): the continuous descent has a terminal
 //                             exit and a trace may end in an existing terminal node (mcts.py:619-623, 682) -- compiled into this
 //                             family only, so that the Pendulum kernels carry no exit mask
+//   AZG_ENV_ACROBOT           discrete actions, SIX observations (Acrobot-v1): the network's first layer takes a second MFMA k-step and
+//                             the workgroup's input block has eight rows; a family of its own so that the CartPole family's kernels
+//                             carry neither (nor the Runge-Kutta dynamics)
 template <int ENV> struct EnvFamily {
-    static constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;            // MCTSContinuous (progressive widening) vs MCTSDiscrete
+    static constexpr bool CONT = ENV == AZG_ENV_PENDULUM_V1 || ENV == AZG_ENV_MOUNTAINCAR_CONT;   // MCTSContinuous (progressive widening) vs MCTSDiscrete
     static constexpr bool TERM = ENV != AZG_ENV_PENDULUM_V1;         // nodes can be terminal
-    static constexpr int S = ENV == AZG_ENV_CARTPOLE ? 4 : 2;        // env state slots the kernels carry
+    static constexpr int S = CONT ? 2 : 4;                           // env state slots the kernels carry
+    static constexpr bool IN8 = ENV == AZG_ENV_ACROBOT;              // five to eight network inputs
 };
 
 // observation of a state; Pendulum also returns sin(theta) so that the node can cache it for its children's dynamics
@@ -96,15 +100,33 @@ __device__ __forceinline__ void mountaincar_cont_step(const double* s, float act
     *reward = (d ? 100.0 : 0.0) - (a * a) * 0.1;
 }
 
-// one step of the discrete family's environment (the kernels are instantiated once per family: ENV = AZG_ENV_CARTPOLE)
+// one step of the discrete family's environment (the kernels are instantiated once per family: ENV = AZG_ENV_CARTPOLE); Acrobot's
+// dynamics live in include/azg_math.h, shared with the oracle
 __device__ __forceinline__ void discrete_env_step(int env_id, const double* s, int action, double* o, double* reward, int* done) {
     if (env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(s, action, o, reward, done);
     else cartpole_step(s, action, o, reward, done);
 }
+// the same for a kernel of env family ENV: the Acrobot family steps Acrobot (include/azg_math.h), the CartPole family never does
+template <int ENV>
+__device__ __forceinline__ void family_env_step(int env_id, const double* s, int action, double* o, double* reward, int* done) {
+    if constexpr (ENV == AZG_ENV_ACROBOT) azg_acrobot_step(s, action, o, reward, done);
+    else discrete_env_step(env_id, s, action, o, reward, done);
+}
 
-// Every step of the discrete family's environments pays the same reward (CartPole +1, MountainCar -1): the tree walk takes a
-// path record's reward from here instead of loading it (the node records still hold it, for dumps and the generic backup).
-__device__ __forceinline__ double discrete_env_reward(int env_id) { return env_id == AZG_ENV_MOUNTAINCAR ? -1.0 : 1.0; }
+// the discrete family's observation of a state as the network sees it: up to eight inputs (CartPole 4, MountainCar 2, Acrobot 6)
+__device__ __forceinline__ void discrete_env_obs(int env_id, const double* s, float* obs8) {
+    if (env_id == AZG_ENV_ACROBOT) { azg_acrobot_obs(s, obs8); obs8[6] = 0.0f; obs8[7] = 0.0f; }
+    else { obs8[0] = (float)s[0]; obs8[1] = (float)s[1]; obs8[2] = (float)s[2]; obs8[3] = (float)s[3]; obs8[4] = obs8[5] = obs8[6] = obs8[7] = 0.0f; }
+}
+
+// Every step of the discrete family's environments that does not end the episode pays the same reward (CartPole +1, MountainCar -1,
+// Acrobot -1): the tree walk takes a path record's reward from here instead of loading it (the node records still hold it, for
+// dumps and the generic backup).  The step INTO a terminal node -- always a trace's last -- pays discrete_env_terminal_reward: the
+// same for CartPole and MountainCar, 0 for Acrobot (gym: `reward = -1. if not terminal else 0.`).
+__device__ __forceinline__ double discrete_env_reward(int env_id) { return env_id == AZG_ENV_CARTPOLE ? 1.0 : -1.0; }
+__device__ __forceinline__ double discrete_env_terminal_reward(int env_id) {
+    return env_id == AZG_ENV_CARTPOLE ? 1.0 : (env_id == AZG_ENV_ACROBOT ? 0.0 : -1.0);
+}
 
 // gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node
 __device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {

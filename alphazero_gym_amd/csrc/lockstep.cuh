@@ -23,7 +23,7 @@
 // g_base = first tree group of the launching pipeline.  FUSE0: compute the first layer in this kernel's tail.
 template <int ENV, bool GMM, int NCH, int HP, bool FUSE0>
 __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int sim, int g_base) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2]
     __shared__ float s_obs[64];         // [4][16] observations of the group's new leaves (FUSE0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;

@@ -94,12 +94,12 @@ static hipError_t ls_run(azg_engine* e) {
 
 template <int ENV>
 static hipError_t ls_dispatch(azg_engine* e) {
-    const bool gmm = ENV != AZG_ENV_CARTPOLE && e->P.ncomp >= 2;
+    const bool gmm = EnvFamily<ENV>::CONT && e->P.ncomp >= 2;
     if (e->HP == 512) {
-        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 512, true>(e); }
+        if constexpr (EnvFamily<ENV>::CONT) { if (gmm) return ls_run<ENV, 512, true>(e); }
         return ls_run<ENV, 512, false>(e);
     }
-    if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return ls_run<ENV, 1024, true>(e); }
+    if constexpr (EnvFamily<ENV>::CONT) { if (gmm) return ls_run<ENV, 1024, true>(e); }
     return ls_run<ENV, 1024, false>(e);
 }
 

@@ -79,7 +79,8 @@ struct WRegs {
     f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
     f32x4 b[NREG > 0 ? NREG : 1][NTW];
     f32x4 wh[NTW];   // head weights of this wave's K-chunk(s)
-    float w0[NW0];   // first layer (K <= 4: one k-step per tile)
+    float w0[NW0];   // first layer, inputs 0..3 (one k-step per tile)
+    float w0b[NW0];  // inputs 4..7 (only read by kernels that serve networks with more than four inputs: mlp_forward's IN8)
     f32x4 b0[NW0];
 };
 
@@ -134,7 +135,9 @@ __device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4
 // publishes it, and the last layer's output feeds the head MFMAs directly.
 // (WR: WRegs<HP, NREG, NW>, or a look-alike that keeps some of the small operands elsewhere -- tools/probes/pair's server)
 // NT: trees per group (16, or fewer: the remaining columns of the tile are fed zeros); obsT is then [4][NT*NG].
-template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>, int NT = 16>
+// IN8: the kernel also serves networks with five to eight inputs (Acrobot: six observations): obsT is [8][NT*NG] and, when P.in8 says
+// so, the first layer takes a second k-step over input rows 4..7 (same accumulator: the k-ordered chain simply goes on).
+template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>, int NT = 16, bool IN8 = false>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, const float* obsT, f32x4* actA, f32x4* actB,
                                             f32x4* parts, float* s_ln, int wave, int lane
 #ifdef AZG_STAMPS
@@ -154,14 +157,23 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
         float b;
         if constexpr (NT == 16) b = obsT[(lane >> 4) * (16 * NG) + g * 16 + (lane & 15)];
         else b = (lane & 15) < NT ? obsT[(lane >> 4) * (NT * NG) + g * NT + (lane & 15)] : 0.0f;
+        float b2 = 0.0f;   // input rows 4..7
+        if constexpr (IN8) {
+            if constexpr (NT == 16) b2 = obsT[(4 + (lane >> 4)) * (16 * NG) + g * 16 + (lane & 15)];
+            else b2 = (lane & 15) < NT ? obsT[(4 + (lane >> 4)) * (NT * NG) + g * NT + (lane & 15)] : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
+            f32x4 a0;
             if constexpr (HP <= 256) {
-                h[g][i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0));
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0);
+                if constexpr (IN8) { if (P.in8) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0b[i], b2, a0, 0, 0, 0); }
             } else {   // wide layers: first-layer weights are not kept in registers
                 const int nt = wave * NTW + i;
-                h[g][i] = act4<NREG == 0>(P.act, __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0));
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0);
+                if constexpr (IN8) { if (P.in8) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0b[nt * 64 + lane], b2, a0, 0, 0, 0); }
             }
+            h[g][i] = act4<NREG == 0>(P.act, a0);
         }
     }
     // LayerNorm is compiled into the weight-streaming kernels only (the host selects them when layernorm is on)

@@ -11,12 +11,12 @@ __global__ __launch_bounds__(256, 1) void mlp_eval_kernel(KParams P, const float
                                                         float* raw) {
     constexpr int NCH = head_chunks<HP>();
     __shared__ f32x4 s_parts[NCH * 64];
-    __shared__ float s_obsT[64];
+    __shared__ float s_obsT[128];   // [8 input rows][16 observations]
     __shared__ float s_bhead[16];
     __shared__ float s_ln[2 * 64];
     extern __shared__ f32x4 s_act[];   // two activation buffers of HP/16 tiles x 64 lanes
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 64) {
+    if (tid < 128) {
         const int k = tid >> 4, row = blockIdx.x * 16 + (tid & 15);
         s_obsT[tid] = (row < n && k < S_obs) ? obs[(size_t)row * S_obs + k] : 0.0f;
     }
@@ -27,15 +27,16 @@ __global__ __launch_bounds__(256, 1) void mlp_eval_kernel(KParams P, const float
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             wr.w0[i] = P.W0[(wave * NTW + i) * 64 + lane];
+            if (P.in8) wr.w0b[i] = P.W0b[(wave * NTW + i) * 64 + lane];
             wr.b0[i] = P.b0[(wave * NTW + i) * 64 + lane];
         }
     }
     __syncthreads();
 #ifdef AZG_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    mlp_forward<HP, 0, 4, 1, 64>(P, wr, s_obsT, s_act, s_act + HP / 16 * 64, s_parts, s_ln, wave, lane, st_acc);
+    mlp_forward<HP, 0, 4, 1, 64, WRegs<HP, 0, 4>, 16, true>(P, wr, s_obsT, s_act, s_act + HP / 16 * 64, s_parts, s_ln, wave, lane, st_acc);
 #else
-    mlp_forward<HP, 0, 4, 1, 64>(P, wr, s_obsT, s_act, s_act + HP / 16 * 64, s_parts, s_ln, wave, lane);
+    mlp_forward<HP, 0, 4, 1, 64, WRegs<HP, 0, 4>, 16, true>(P, wr, s_obsT, s_act, s_act + HP / 16 * 64, s_parts, s_ln, wave, lane);
 #endif
     const int row = blockIdx.x * 16 + tid;
     if (tid >= 16 || row >= n) return;

@@ -95,7 +95,9 @@ struct KParams {
     const double* sqrt_tab;  // [tab_n]  sqrt(n+1)
     const f32x4* W0u;        // [HP] first layer per unit: (w[u][0], w[u][1], w[u][2], w[u][3]) -- the VALU form of the first layer
     const f32x4* b0u;        // [HP/4] first-layer bias, four consecutive units per entry
-    const float* W0;         // [HP/16][64]
+    const float* W0;         // [HP/16][64]   first layer, inputs 0..3 (one MFMA k-step: lane l = unit l & 15, input l >> 4)
+    const float* W0b;        // [HP/16][64]   inputs 4..7 (networks with more than four inputs: Acrobot's six observations)
+    int in8;                 // the network has more than four inputs: the first layer takes a second k-step (W0b, observation rows 4..7)
     const f32x4* b0;         // [HP/16][64]
     const f32x4* Wl[MAX_STREAM_LAYERS]; // hidden->hidden layer l (1-based index l-1): [HP/16 tiles][HP/16 s4][64]
     const f32x4* bl[MAX_STREAM_LAYERS]; // [HP/16][64]

@@ -44,7 +44,7 @@ __host__ __device__ constexpr int act_buffers(int NREG) { return NREG == 1 ? 1 :
 // SPEC: compile-time knowledge about run-time parameters (tree_phases.cuh: Spec<>; 0 = the general code)
 template <int ENV, int HP, int NREG, int TLDS, bool GMM, int NW, int NG, int NT = 16, int SPEC = 0>
 __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParams P) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     static_assert(NT == 16 || (NG == 1 && NW == 4 && (NT == 8 || NT == 4)), "half-filled tiles: one group, four waves");
     constexpr int TPW = NT * NG;        // trees per workgroup
     // NW = 8, NG = 1 (one 16-tree group, eight waves): all eight waves share the network phase -- a tile fewer each, and the two
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     constexpr int NCH = head_chunks<HP>();   // partial head sums per tree
     constexpr int PSTR = GMM ? 64 : 16;      // entries kept per chunk: all 16 output rows, or rows 0..3 (value + Normal / 2 actions)
     __shared__ f32x4 s_parts[NG * NCH * PSTR];
-    __shared__ float s_obsT[4 * TPW];
+    // the Acrobot family: six observations -- eight input rows, a second k-step in the network's first layer (KParams::in8 is set)
+    constexpr bool IN8 = EnvFamily<ENV>::IN8;
+    __shared__ float s_obsT[(IN8 ? 8 : 4) * TPW];
     __shared__ float s_bhead[16];
     __shared__ float s_ln[NREG == 0 ? 2 * 64 : 1];
     __shared__ int s_done;              // discrete mode: trees of this workgroup that have finished their last trace
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             wr.w0[i] = P.W0[(wave * NTW + i) * 64 + lane];
+            if constexpr (IN8) { if (P.in8) wr.w0b[i] = P.W0b[(wave * NTW + i) * 64 + lane]; }
             wr.b0[i] = P.b0[(wave * NTW + i) * 64 + lane];
         }
     }
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
 #endif
     TreeState st = {};
     st.need_eval = false;
-    if (cx.has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tree, cx.live, cx.sub, cx.tl, cx.gtree, s_obsT);
+    if (cx.has_tree) tree_init_root<ENV, TLDS, TPW, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tree, cx.live, cx.sub, cx.tl, cx.gtree, s_obsT);
     __syncthreads();
 
     // Discrete mode: a tree's traces need a network evaluation only when they create a non-terminal node (CartPole at config B: one
@@ -184,9 +187,9 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3));
         }
 #ifdef AZG_STAMPS
-        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT, IN8>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
 #else
-        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT, IN8>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
 #endif
         STAMP(t_c);
         if constexpr (LEAN) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             // the path's rewards and cumulative returns (the descent did not fetch them: tree_phase_b<..., FETCH = false>)
             st.pr = 0.0; st.pW = 0.0;
             if (cx.live && (MULTI ? my_sim : sim) >= 0 && st.my_depth >= 1) {
-                st.pr = CONT ? cx.cold[st.pid].r : discrete_env_reward(Spec<SPEC>::env(P));
+                st.pr = CONT ? cx.cold[st.pid].r : discrete_env_reward(Spec<SPEC, ENV>::env(P));
                 st.pW = cx.edge_W[st.pid];
             }
         }
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             STAMP(t_d);
             // ================= tree phase B: next trace: select down, step the env, expand =================
             st.need_eval = false;
-            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
             __threadfence_block();
             STAMP(t_e);
             STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
                     run = false;
                 } else {
                     my_sim += 1;
-                    tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
+                    tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
                     __threadfence_block();
                     k += 1;
                     if (st.need_eval || k >= P.trace_cap) run = false;

@@ -108,7 +108,7 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
 // SPEC: compile-time knowledge about run-time parameters for the tree phases (tree_phases.cuh: Spec<>; 0 = the general code).
 template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2, int SPEC = 0>
 __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int NU = HP / 64, NCH = HP / 64;
     constexpr int TPW = 32 / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
     static_assert(TPW >= 1 && TPW <= 4, "a team is 32 trees over HP/64 workgroups");

@@ -12,7 +12,7 @@
 template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0>
 static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     constexpr int NU = HP / 64, TPW = 32 / NU;
-    constexpr bool CONT = ENV != AZG_ENV_CARTPOLE;
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
     const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
     const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
@@ -89,13 +89,13 @@ static hipError_t team_storage(azg_engine* e) {
 
 template <int ENV>
 static hipError_t team_dispatch(azg_engine* e) {
-    const bool gmm = ENV != AZG_ENV_CARTPOLE && e->P.ncomp >= 2;
+    const bool gmm = EnvFamily<ENV>::CONT && e->P.ncomp >= 2;
     if (e->HP == 512) {
-        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return team_storage<ENV, 512, true>(e); }
+        if constexpr (EnvFamily<ENV>::CONT) { if (gmm) return team_storage<ENV, 512, true>(e); }
         return team_storage<ENV, 512, false>(e);
     }
     if (e->HP == 1024) {
-        if constexpr (ENV != AZG_ENV_CARTPOLE) { if (gmm) return team_storage<ENV, 1024, true>(e); }
+        if constexpr (EnvFamily<ENV>::CONT) { if (gmm) return team_storage<ENV, 1024, true>(e); }
         return team_storage<ENV, 1024, false>(e);
     }
     return hipErrorNotReady;

@@ -231,12 +231,13 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 // On return pW holds the slot's updated W and `rec` the slot's updated record (zeros in lanes without a slot); `chainR` is the
 // lane's return of this trace.  same_chain: the trace is the previous one again (same path, same terminal leaf, see
 // tree_phase_b): every lane's return is the one it had, the serial chain is skipped.  r_uniform (discrete mode): the reward every
-// edge carries (env.cuh: discrete_env_reward) -- equal to pr in every lane that holds a slot.
+// edge of the path carries (env.cuh: discrete_env_reward) except the last one, the edge into the leaf, which carries r_first (the
+// same value unless the leaf is terminal and the env pays differently on its last step: Acrobot).
 template <bool CONT, int TLDS, typename F>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
                                             double gamma, int D, int my_depth, int pid, double pr, double& pW, F&& on_node,
                                             typename TreeStore<TLDS>::Rec& rec, double& chainR, bool same_chain = false,
-                                            double r_uniform = 0.0) {
+                                            double r_uniform = 0.0, double r_first = 0.0) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
@@ -254,14 +255,14 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
             R = (double)V;
 #pragma unroll 2
             for (int d = 0; d < n0; ++d) {
-                R = r_uniform + R;
+                R = (d == 0 ? r_first : r_uniform) + R;
                 if (sub == ((D - d) & 15)) myR = R;
             }
         } else {
 #pragma unroll 2
             for (int d = 0; d < n0; ++d) {
                 const double gR = d == 0 ? gamma * (double)V : gamma * R;
-                R = r_uniform + gR;
+                R = (d == 0 ? r_first : r_uniform) + gR;
                 if (sub == ((D - d) & 15)) myR = R;
             }
         }

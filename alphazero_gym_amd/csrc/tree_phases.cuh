@@ -27,12 +27,15 @@ struct TreeState {
 // configurations run on; SPEC = 0 is the general code, same results): no epsilon-greedy selection, lowest-index ties; the discrete
 // family: CartPole with its two actions and no carried root count beyond the sqrt table; the Pendulum family: Pendulum-v1.  Every test on those parameters then folds away: no scalar compare / branch /
 // exec-mask bookkeeping around paths that are never taken, fewer values kept live in scalar registers.
-template <int SPEC> struct Spec {
+// (ENV: the kernel's env family -- the Acrobot family knows its env and its three actions at compile time whatever SPEC says)
+template <int SPEC, int ENV = AZG_ENV_CARTPOLE> struct Spec {
     static __device__ __forceinline__ bool eps0(const KParams& P) { return SPEC ? true : P.epsilon == 0.0; }
     static __device__ __forceinline__ bool tie_random(const KParams& P) { return SPEC ? false : P.tie_random != 0; }
     static __device__ __forceinline__ bool plain(const KParams& P) { return SPEC ? true : (P.epsilon == 0.0 && !P.tie_random); }
-    static __device__ __forceinline__ int A(const KParams& P) { return SPEC ? 2 : P.A; }                          // (discrete family)
-    static __device__ __forceinline__ int env(const KParams& P) { return SPEC ? (int)AZG_ENV_CARTPOLE : P.env_id; }   // (discrete family)
+    static __device__ __forceinline__ int A(const KParams& P) { return ENV == AZG_ENV_ACROBOT ? 3 : (SPEC ? 2 : P.A); }   // (discrete families)
+    static __device__ __forceinline__ int env(const KParams& P) {                                                       // (discrete families)
+        return ENV == AZG_ENV_ACROBOT ? (int)AZG_ENV_ACROBOT : (SPEC ? (int)AZG_ENV_CARTPOLE : P.env_id);
+    }
     static __device__ __forceinline__ int v1(const KParams& P) { return SPEC ? 1 : P.v1; }                         // (Pendulum family: Pendulum-v1)
     // every node count the search can meet lies inside the host-built sqrt(n + 1) table (no carried root count beyond it)
     static __device__ __forceinline__ bool in_table(const KParams& P, int n) { return SPEC ? true : n < P.tab_n; }
@@ -70,12 +73,12 @@ template <bool CONT> __device__ __forceinline__ void set_best(RecL* r, const Rec
 template <int ENV, int TLDS, typename Rec, int SPEC = 0>
 __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TLDS>& ts, int p, const Rec& hp, int sub, const double* s_sqrt,
                                             int pick, unsigned gtree = 0u) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     const int K = hp.n_child;
     // sqrt(n + 1): host-built table; a reused root that was searched many times without moving on (discrete mode) can
     // carry a count beyond the table, then the correctly rounded square root is computed in place
     double sq;
-    if (CONT || Spec<SPEC>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
+    if (CONT || Spec<SPEC, ENV>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
     int win_c = 0;
     if (TLDS || K <= 16) {   // (LDS trees have at most 16 children per node)
@@ -97,7 +100,7 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
         if (!SPEC && pick >= 0) win_c = __shfl(c, pick, 16);
         else if (!CONT && K == 2) win_c = argmax2_payload(U, sub, c);
         else win_c = argmax16_payload(U, valid, sub, c);
-        if (Spec<SPEC>::tie_random(P) && pick < 0) {
+        if (Spec<SPEC, ENV>::tie_random(P) && pick < 0) {
             // helpers.argmax (helpers.py:46-52): uniform among the children that hold the maximum.  The draw is keyed by the node
             // and its visit count: between two visits of a node nothing its scores depend on changes.
             const double m = rowmax16(U, valid);
@@ -146,7 +149,7 @@ __device__ __forceinline__ int select_child(const KParams& P, const TreeStore<TL
 // Re-take the selection of node p after its statistics changed and store it with the node (lane 0 of the tree writes).
 template <int ENV, int TLDS, int SPEC = 0>
 __device__ __forceinline__ void refresh_best(const KParams& P, const TreeStore<TLDS>& ts, int p, int sub, const double* s_sqrt) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     typedef typename TreeStore<TLDS>::Rec Rec;
     const Rec hp = ts.hot[p];
     const int b = select_child<ENV, TLDS, Rec, SPEC>(P, ts, p, hp, sub, s_sqrt, -1);
@@ -164,7 +167,7 @@ __device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const Tre
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int p = mine ? pid : 0;
     double sq;
-    if (Spec<SPEC>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
+    if (Spec<SPEC, ENV>::in_table(P, (int)hp.node_n)) sq = s_sqrt[hp.node_n];
     else sq = __builtin_sqrt((double)((int)hp.node_n + 1));
     const int c0 = (int)hp.first;
     const Rec h0 = ts.hot[c0], h1 = ts.hot[c0 + 1];
@@ -179,10 +182,12 @@ __device__ __forceinline__ int refresh_best_own_slot(const KParams& P, const Tre
 
 // initialize_search + the root's observation (mcts.py:364-383, 589-600); obsT is the [4][TPW] input block of the tree's
 // workgroup (TPW trees per workgroup, tl = the tree's index in it)
-template <int ENV, int TLDS, int TPW = 16>
+// OBS8: the workgroup's input block has eight rows (obsT [8][TPW]) and the env is asked for up to eight observations (discrete family,
+// general kernels: Acrobot's six)
+template <int ENV, int TLDS, int TPW = 16, bool OBS8 = false>
 __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                                float* action, int tree, bool live, int sub, int tl, unsigned gtree, float* obsT) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
@@ -192,8 +197,9 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
         double rs[S], sn;
 #pragma unroll
         for (int k = 0; k < S; ++k) rs[k] = (live && k < P.S) ? P.roots[(size_t)tree * P.S + k] : 0.0;   // (P.S: the env's own state width)
-        float obs[4];
-        env_obs<ENV>(rs, obs, &sn);
+        float obs[OBS8 ? 8 : 4];
+        if constexpr (OBS8) { sn = 0.0; azg_acrobot_obs(rs, obs); obs[6] = 0.0f; obs[7] = 0.0f; }
+        else env_obs<ENV == AZG_ENV_ACROBOT ? AZG_ENV_CARTPOLE : ENV>(rs, obs, &sn);
         if (live && sub == 0) {
             Rec h = make_edge<Rec>(0.0, 0);
             h.node_n = (decltype(h.node_n))P.carry[tree];
@@ -215,7 +221,13 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
                 }
             }
         }
-        if (sub < 4) obsT[sub * TPW + tl] = live ? obs[sub] : 0.0f;
+        if constexpr (!OBS8) {
+            if (sub < 4) obsT[sub * TPW + tl] = live ? obs[sub] : 0.0f;
+        } else if (sub < 8) {   // (eight input rows)
+            float v = sub == 0 ? obs[0] : (sub == 1 ? obs[1] : (sub == 2 ? obs[2] : obs[3]));
+            if (sub >= 4) v = sub == 4 ? obs[4] : (sub == 5 ? obs[5] : (sub == 6 ? obs[6] : obs[7]));
+            obsT[sub * TPW + tl] = live ? v : 0.0f;
+        }
 }
 
 // Phase A: give the evaluated leaf its value / policy (evaluation, add_value_estimate: mcts.py:385-416, 602-623; the root's first
@@ -226,7 +238,7 @@ template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = fal
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
                                              const float* bhead, const double* s_sqrt STAMP_PARAM_OPT) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
     STAMP_A(ta0);
@@ -271,7 +283,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
             }
         } else {
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
-            const int A = Spec<SPEC>::A(P);
+            const int A = Spec<SPEC, ENV>::A(P);
             // (logits 1 .. 3 come with out4; further actions, should an environment have them, through head_output)
             // lane a < A works on action a: its logit, its exp; the maximum and the sum are taken in action order (the sum as
             // ((0 + e_0) + e_1) + ..., the reference's order) from the lanes' values
@@ -307,13 +319,13 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 ts.hot[st.leaf].n_child = (decltype(ts.hot[st.leaf].n_child))A;
                 ts.hot[st.leaf].first = (decltype(ts.hot[st.leaf].first))k0;
             }
-            if (Spec<SPEC>::plain(P)) {
+            if (Spec<SPEC, ENV>::plain(P)) {
                 // the new node's own selection (refresh_best): its edges all start at Q = V with no visits, so its scores
                 // are V + (prior_a * c_uct as float32) * (sqrt(n + 1) / 1) -- a division by one is exact
                 if (A == 2) {
                     const int nn = (int)ts.hot[st.leaf].node_n;   // 0, or the carried count of a reused root
                     double sq;
-                    if (Spec<SPEC>::in_table(P, nn)) sq = s_sqrt[nn];
+                    if (Spec<SPEC, ENV>::in_table(P, nn)) sq = s_sqrt[nn];
                     else sq = __builtin_sqrt((double)(nn + 1));
                     float prior_s = 0.0f;
                     if (sub < A) prior_s = e_mine / sum;
@@ -332,12 +344,14 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     STAMP_A_ADD(4, ta0, ta1);   // finish leaf
     if (sim >= 0) {
         if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
-        const bool keep = !CONT && Spec<SPEC>::plain(P);   // (cached selections: discrete mode, see rec_best)
+        const bool keep = !CONT && Spec<SPEC, ENV>::plain(P);   // (cached selections: discrete mode, see rec_best)
         Rec myrec;
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
                                 [&](int pn) { if (keep) refresh_best<ENV, TLDS, SPEC>(P, ts, pn, sub, s_sqrt); }, myrec, st.chainR,
                                 RESUME && !CONT && st.repeat,    // (only the kernels that resume descents set st.repeat)
-                                CONT ? 0.0 : discrete_env_reward(Spec<SPEC>::env(P)));
+                                CONT ? 0.0 : discrete_env_reward(Spec<SPEC, ENV>::env(P)),
+                                // (a pending leaf that needs no evaluation is a terminal node: need_eval = !done)
+                                CONT ? 0.0 : (st.need_eval ? discrete_env_reward(Spec<SPEC, ENV>::env(P)) : discrete_env_terminal_reward(Spec<SPEC, ENV>::env(P))));
         STAMP_A(ta2);
         STAMP_A_ADD(5, ta1, ta2);   // backup (return chain, record updates)
         if constexpr (!CONT) {
@@ -346,7 +360,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 // (anything deeper than 16 levels was refreshed by backup_from through the callback above)
                 const int D = st.path_D, lo = D > 15 ? D - 15 : 0;
                 if (!TLDS) __threadfence_block();
-                if (Spec<SPEC>::A(P) == 2) {
+                if (Spec<SPEC, ENV>::A(P) == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
                     const bool mine = st.my_depth >= lo && st.my_depth < D;
                     const int win = refresh_best_own_slot<ENV, TLDS, SPEC>(P, ts, st.pid, mine, s_sqrt, myrec);
@@ -375,11 +389,11 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 // FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
 // RESUME (discrete mode, cached selections): the descent starts where the last trace's path is left (st.resume, set by
 // tree_phase_a<..., RESUME = true>) instead of at the root; the path slots above that depth are still in the lanes.
-template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0>
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0, bool OBS8 = false>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM) {
-    constexpr bool CONT = (ENV != AZG_ENV_CARTPOLE);
+    constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.need_eval = false;
@@ -391,7 +405,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     bool resumed = false;
     st.repeat = false;
     if constexpr (RESUME && !CONT) {
-        if (Spec<SPEC>::plain(P) && Spec<SPEC>::A(P) == 2 && st.resume > 0) {
+        if (Spec<SPEC, ENV>::plain(P) && Spec<SPEC, ENV>::A(P) == 2 && st.resume > 0) {
             // same path as a descent from the root down to depth `resume` (tree_phase_a): go on from that node
             resumed = true;
             p = __shfl(st.pid, st.resume, 16);
@@ -401,7 +415,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     }
     // discrete mode: every step of the env pays the same reward, and a path slot that survives from the last trace (depths 1 ..
     // resume) still holds its record's W as the last backup left it: only records that enter the path are fetched
-    const double r_step = CONT ? 0.0 : discrete_env_reward(Spec<SPEC>::env(P));
+    const double r_step = CONT ? 0.0 : discrete_env_reward(Spec<SPEC, ENV>::env(P));
     const bool keep_slot = !CONT && FETCH && resumed && st.my_depth >= 1;
     Rec hp = ts.hot[p];
     Cold cp;             // cold part of the current node, prefetched one level ahead
@@ -426,10 +440,10 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
             if (widen) break;
         }
-        if (CONT || !Spec<SPEC>::plain(P)) {
+        if (CONT || !Spec<SPEC, ENV>::plain(P)) {
             // scored on the way down (continuous mode; epsilon-greedy selection, MCTS.epsilon_greedy mcts.py:190-195; random ties)
             int pick = -1;
-            if (!Spec<SPEC>::eps0(P)) {
+            if (!Spec<SPEC, ENV>::eps0(P)) {
                 azg_u32x4 b = azg_draw(P.seed, gtree, P.search_idx, st.eps_draws++, AZG_STREAM_EPS);
                 if ((double)azg_u01(b.v[0]) < P.epsilon) pick = (int)(b.v[1] % (unsigned)K);
             }
@@ -509,20 +523,21 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (CONT) {
             if (!widen) cact = action[chosen];
             if constexpr (ENV == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(cp.s, cact, ns, &r, &done);
-            else pendulum_step(Spec<SPEC>::v1(P), cp.s, cp.s[2], cact, ns, &r, &done);
+            else pendulum_step(Spec<SPEC, ENV>::v1(P), cp.s, cp.s[2], cact, ns, &r, &done);
             r = r / P.reward_scale;   // mcts.py:687 (whatever the env: the reference divides every continuous reward by PENDULUM_R_SCALE)
         } else {
             if constexpr (TLDS != TS_GLOBAL) {
                 if (ts.state) {
-                    const int slot = Spec<SPEC>::A(P) == 2 ? ((int)hp.first - 1) >> 1 : ((int)hp.first - 1) / P.A;
+                    const int slot = Spec<SPEC, ENV>::A(P) == 2 ? ((int)hp.first - 1) >> 1 : ((int)hp.first - 1) / P.A;
                     const double* sp = ts.state + 4 * slot;
                     cp.s[0] = sp[0]; cp.s[1] = sp[1]; cp.s[2] = sp[2]; cp.s[3] = sp[3];
                 }
             }
-            discrete_env_step(Spec<SPEC>::env(P), cp.s, chosen - (int)hp.first, ns, &r, &done);
+            family_env_step<ENV>(Spec<SPEC, ENV>::env(P), cp.s, chosen - (int)hp.first, ns, &r, &done);
         }
-        float obs[4];
-        env_obs<ENV>(ns, obs, &sn);
+        float obs[OBS8 ? 8 : 4];
+        if constexpr (OBS8) { sn = 0.0; azg_acrobot_obs(ns, obs); obs[6] = 0.0f; obs[7] = 0.0f; }
+        else env_obs<ENV == AZG_ENV_ACROBOT ? AZG_ENV_CARTPOLE : ENV>(ns, obs, &sn);
         STAMP_ENV(tw2);
         STAMP_ENV_ADD(15, tw1, tw2);   // env step + observation
         if (sub == 0) {
@@ -537,7 +552,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
             if constexpr (!CONT && TLDS != TS_GLOBAL) {
                 if (ts.state && !done) {   // the next node to be evaluated in this tree: its edges will start at record nrec
-                    double* sp = ts.state + 4 * (Spec<SPEC>::A(P) == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
+                    double* sp = ts.state + 4 * (Spec<SPEC, ENV>::A(P) == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sp[k] = ns[k];
                 }
@@ -546,6 +561,12 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (sub == (st.path_D & 15)) { st.my_depth = st.path_D; st.pid = chosen; st.pr = r; st.pW = 0.0; }
         st.leaf = chosen;
         st.need_eval = !done;
-        if (sub < 4) obsT[sub * TPW + tl] = done ? 0.0f : obs[sub];
+        if constexpr (!OBS8) {
+            if (sub < 4) obsT[sub * TPW + tl] = done ? 0.0f : obs[sub];
+        } else if (sub < 8) {
+            float v = sub == 0 ? obs[0] : (sub == 1 ? obs[1] : (sub == 2 ? obs[2] : obs[3]));
+            if (sub >= 4) v = sub == 4 ? obs[4] : (sub == 5 ? obs[5] : (sub == 6 ? obs[6] : obs[7]));
+            obsT[sub * TPW + tl] = done ? 0.0f : v;
+        }
     }
 }

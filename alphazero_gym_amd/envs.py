@@ -2,7 +2,7 @@
 
 The reference gets its environments from the third-party ``gym`` package (``rl/make_game.py:49-68``,
 ``gym==0.19.0`` in requirements.txt:10), which is neither vendored in the reference nor installed here.
-These classes restate the published CartPole / MountainCar / MountainCarContinuous / Pendulum dynamics with the gym 0.19 ``Env`` call
+These classes restate the published CartPole / MountainCar / MountainCarContinuous / Acrobot / Pendulum dynamics with the gym 0.19 ``Env`` call
 surface the reference's MCTS uses: ``copy.deepcopy(Env)`` + ``Env.step(action)`` returning
 ``(obs, reward, done, info)`` (alphazero/search/mcts.py:443-449, 680-687), ``Env.reset()``, ``Env.seed()``.
 
@@ -20,6 +20,7 @@ ENV_PENDULUM_V0 = 1
 ENV_PENDULUM_V1 = 2
 ENV_MOUNTAINCAR = 3
 ENV_MOUNTAINCAR_CONT = 4
+ENV_ACROBOT = 5
 
 
 class _Box:
@@ -142,6 +143,76 @@ class MountainCarEnv(_EnvBase):
         return np.array(self.state, dtype=np.float32), -1.0, done, {}
 
 
+class AcrobotEnv(_EnvBase):
+    """gym ``Acrobot-v1``: two links, three discrete torques (-1, 0, +1) on the joint between them, SIX observations
+    ``(cos t1, sin t1, cos t2, sin t2, dt1, dt2)``, reward -1 per step and 0 on the step that ends the episode (the tip above the line:
+    ``-cos t1 - cos(t1 + t2) > 1``).  gym 0.19's "book" dynamics integrated by one classical Runge-Kutta step of 0.2 s (its ``rk4``), then
+    angles wrapped into [-pi, pi] and velocities bounded to +-4 pi / +-9 pi; no torque noise.  All masses, lengths and inertias are 1, the
+    centres of mass sit at 0.5 and g = 9.8: the constants are multiplied out below in gym's own order of operations wherever a factor
+    is not exactly 1, on python floats (gym works on numpy float64 scalars: the same arithmetic) -- this method is the definition the C
+    oracle and the device kernels mirror (include/azg_math.h: azg_acrobot_dsdt / azg_acrobot_step)."""
+
+    azg_env_id = ENV_ACROBOT
+    dt = 0.2
+    MAX_VEL_1 = 4 * math.pi
+    MAX_VEL_2 = 9 * math.pi
+    AVAIL_TORQUE = (-1.0, 0.0, +1.0)
+
+    def __init__(self, state=None):
+        high = np.array([1.0, 1.0, 1.0, 1.0, self.MAX_VEL_1, self.MAX_VEL_2], dtype=np.float32)
+        self.observation_space = _Box(-high, high, (6,))
+        self.action_space = _Discrete(3)
+        self.seed(None)
+        self.state = None if state is None else np.asarray(state, dtype=np.float64)
+
+    def reset(self):
+        self.state = self.np_random.uniform(low=-0.1, high=0.1, size=(4,))
+        return self._get_ob()
+
+    def _get_ob(self):
+        s = self.state
+        return np.array([math.cos(s[0]), math.sin(s[0]), math.cos(s[1]), math.sin(s[1]), s[2], s[3]])
+
+    @staticmethod
+    def _dsdt(s, a):
+        g = 9.8
+        theta1, theta2, dtheta1, dtheta2 = s
+        cs2, sn2 = math.cos(theta2), math.sin(theta2)
+        d1 = ((0.25 + (1.25 + cs2)) + 1.0) + 1.0
+        d2 = (0.25 + 0.5 * cs2) + 1.0
+        phi2 = (0.5 * g) * math.cos((theta1 + theta2) - math.pi / 2.0)
+        phi1 = ((-(0.5 * (dtheta2 * dtheta2)) * sn2 - ((1.0 * dtheta2) * dtheta1) * sn2) + (1.5 * g) * math.cos(theta1 - math.pi / 2.0)) + phi2
+        ddtheta2 = (((a + (d2 / d1) * phi1) - (0.5 * (dtheta1 * dtheta1)) * sn2) - phi2) / ((0.25 + 1.0) - (d2 * d2) / d1)
+        ddtheta1 = -(d2 * ddtheta2 + phi1) / d1
+        return (dtheta1, dtheta2, ddtheta1, ddtheta2)
+
+    def _terminal(self):
+        s = self.state
+        return bool(-math.cos(s[0]) - math.cos(s[1] + s[0]) > 1.0)
+
+    def step(self, action):
+        s = tuple(float(v) for v in self.state)
+        a = self.AVAIL_TORQUE[int(action)]
+        dt, dt2 = self.dt, self.dt / 2.0
+        k1 = self._dsdt(s, a)
+        k2 = self._dsdt(tuple(s[i] + dt2 * k1[i] for i in range(4)), a)
+        k3 = self._dsdt(tuple(s[i] + dt2 * k2[i] for i in range(4)), a)
+        k4 = self._dsdt(tuple(s[i] + dt * k3[i] for i in range(4)), a)
+        ns = [s[i] + (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]) for i in range(4)]
+        for i in range(2):   # wrap(x, -pi, pi)
+            x = ns[i]
+            while x > math.pi:
+                x = x - 2.0 * math.pi
+            while x < -math.pi:
+                x = x + 2.0 * math.pi
+            ns[i] = x
+        ns[2] = min(max(ns[2], -self.MAX_VEL_1), self.MAX_VEL_1)
+        ns[3] = min(max(ns[3], -self.MAX_VEL_2), self.MAX_VEL_2)
+        self.state = np.array(ns)
+        terminal = self._terminal()
+        return self._get_ob(), (-1.0 if not terminal else 0.0), terminal, {}
+
+
 class MountainCarContinuousEnv(_EnvBase):
     """gym ``MountainCarContinuous-v0`` (``Continuous_MountainCarEnv``): one continuous action in [-1, 1], episodes END at the flag
     (position >= 0.45 with velocity >= 0) -- the env through which the continuous search meets terminal nodes (mcts.py:619-623,
@@ -258,7 +329,9 @@ def make_game(game: str):
         return MountainCarEnv()
     if name == "mountaincarcontinuous":
         return MountainCarContinuousEnv()
-    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole, MountainCar(Continuous) and Pendulum only")
+    if name == "acrobot":
+        return AcrobotEnv()
+    raise ValueError(f"unsupported game {game!r}: this engine ships closed-form CartPole, MountainCar(Continuous), Acrobot and Pendulum only")
 
 
 class VecPendulum:

@@ -208,7 +208,8 @@ class DeviceSelfPlay:
                                     gamma=gamma, epsilon=epsilon, c_pw=c_pw, kappa=kappa, V_target_policy=V_target_policy,
                                     action_bound=float(policy.action_bound), seed=seed, tree_id_base=rank * n_games, device_id=device_id)
         else:
-            env_id = _capi.ENV_MOUNTAINCAR if game.lower().startswith("mountaincar") else _capi.ENV_CARTPOLE   # (MountainCar-v0)
+            g = game.lower()
+            env_id = _capi.ENV_MOUNTAINCAR if g.startswith("mountaincar") else (_capi.ENV_ACROBOT if g.startswith("acrobot") else _capi.ENV_CARTPOLE)
             self.mcts = BatchedMCTS(policy, env_id=env_id, mode=_capi.MODE_DISCRETE, n_trees=n_games, n_rollouts=n_rollouts,
                                     c_uct=c_uct, gamma=gamma, epsilon=epsilon, num_actions=policy.num_actions,
                                     V_target_policy=V_target_policy, seed=seed, tree_id_base=rank * n_games, device_id=device_id)

@@ -28,14 +28,27 @@ def env_signature(env) -> Tuple[int, np.ndarray]:
         return _capi.ENV_CARTPOLE, np.asarray(u.state, dtype=np.float64)
     if name == "MountainCarEnv":
         return _capi.ENV_MOUNTAINCAR, np.asarray(u.state, dtype=np.float64)
+    if name == "AcrobotEnv":
+        return _capi.ENV_ACROBOT, np.asarray(u.state, dtype=np.float64)
     if name == "Continuous_MountainCarEnv":
         return _capi.ENV_MOUNTAINCAR_CONT, np.asarray(u.state, dtype=np.float64)
     if name == "PendulumEnv":
         spec = getattr(getattr(u, "spec", None), "id", "") or ""
         return (_capi.ENV_PENDULUM_V0 if spec.endswith("v0") else _capi.ENV_PENDULUM_V1), np.asarray(u.state, dtype=np.float64)
     raise NotImplementedError(
-        f"{name}: the engine steps CartPole, MountainCar, MountainCarContinuous and Pendulum in closed form on the GPU; other "
+        f"{name}: the engine steps CartPole, MountainCar, MountainCarContinuous, Acrobot and Pendulum in closed form on the GPU; other "
         "environments are not supported")
+
+
+def env_observation(env_id: int, st: np.ndarray) -> np.ndarray:
+    """float32 observation the reference's nodes keep as ``state`` for an engine state: Acrobot observes (cos, sin) of both joint
+    angles and the two velocities (gym acrobot.py _get_ob), Pendulum (cos, sin, thdot); the others observe their state."""
+    st = np.asarray(st, dtype=np.float64)
+    if env_id == _capi.ENV_ACROBOT:
+        return np.array([np.cos(st[0]), np.sin(st[0]), np.cos(st[1]), np.sin(st[1]), st[2], st[3]], dtype=np.float32)
+    if env_id in (_capi.ENV_PENDULUM_V0, _capi.ENV_PENDULUM_V1):
+        return np.array([np.cos(st[0]), np.sin(st[0]), st[1]], dtype=np.float32)
+    return st.astype(np.float32)
 
 
 def _weights_version(model) -> Tuple:
@@ -213,8 +226,8 @@ class MCTSDiscrete(MCTS):
     def _row(self, i: int):
         r = self._res
         k = int(r["n_children"][i])
-        state = self.root_state if (len(self._envs) == 1 and self.root_state is not None) else np.asarray(
-            env_signature(self._envs[i])[1], dtype=np.float32)
+        state = self.root_state if (len(self._envs) == 1 and self.root_state is not None) else env_observation(
+            *env_signature(self._envs[i]))
         return (state, np.arange(k), r["counts"][i, :k].astype(np.int64), r["Q"][i, :k].copy(), float(r["v_target"][i]))
 
     def forward(self, action: int, state: np.ndarray) -> None:
@@ -224,7 +237,8 @@ class MCTSDiscrete(MCTS):
         if child_n[0, action] < 0:
             self.root_node = None
             self.root_state = state
-        elif np.linalg.norm(child_state[0, action].astype(np.float32) - np.asarray(state, dtype=np.float32)) > 0.01:
+        elif np.linalg.norm(env_observation(env_signature(self._envs[0])[0], child_state[0, action])
+                            - np.asarray(state, dtype=np.float32)) > 0.01:
             print("Warning: this domain seems stochastic. Not re-using the subtree for next search. "
                   + "To deal with stochastic environments, implement progressive widening.")
             self.root_node = None

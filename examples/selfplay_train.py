@@ -35,7 +35,8 @@ def build_agent(game, hidden, n_rollouts, device, lr):
         mcts = dict(cfg["mcts"], n_rollouts=n_rollouts, device=device)
         return ContinuousAgent(policy_cfg=policy, mcts_cfg=mcts, loss_cfg=loss, optimizer_cfg=opt, device=device, **cfg["agent"]), 3
     cfg = run.DISCRETE_DEFAULTS
-    obs_dim, n_act = (2, 3) if game.lower().startswith("mountaincar") else (4, 2)   # MountainCar-v0: three actions
+    g = game.lower()   # MountainCar-v0: two observations, three actions; Acrobot-v1: six observations, three actions
+    obs_dim, n_act = (2, 3) if g.startswith("mountaincar") else ((6, 3) if g.startswith("acrobot") else (4, 2))
     policy = dict(cfg["policy"], hidden_dimensions=hidden, representation_dim=obs_dim, action_dim=1, num_actions=n_act)
     mcts = dict(cfg["mcts"], n_rollouts=n_rollouts, device=device, num_actions=n_act)
     return DiscreteAgent(policy_cfg=policy, mcts_cfg=mcts, loss_cfg=loss, optimizer_cfg=opt, device=device, **cfg["agent"]), obs_dim

@@ -27,8 +27,10 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define AZG_HD __host__ __device__ __forceinline__
+#define AZG_UNROLL _Pragma("unroll")   /* (small fixed-size arrays must stay in registers on the device) */
 #else
 #define AZG_HD static inline
+#define AZG_UNROLL
 #endif
 
 #define AZG_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -224,6 +226,70 @@ AZG_HD azg_u32x4 azg_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
     return r;
 }
 
+/* gym Acrobot-v1 ("book" dynamics, torque noise 0; all link masses / lengths / inertias 1, centres of mass at 0.5, g = 9.8):
+ * the derivative of (theta1, theta2, dtheta1, dtheta2) under torque a, with the constants multiplied out in gym's own order of
+ * operations where a factor is not exactly 1 (alphazero_gym_amd/envs.py AcrobotEnv._dsdt is the definition; this is its mirror). */
+AZG_HD void azg_acrobot_dsdt(const double* s, double a, double* ds) {
+    const double pi = 3.141592653589793, g = 9.8;
+    const double theta1 = s[0], theta2 = s[1], dtheta1 = s[2], dtheta2 = s[3];
+    double sn2, cs2, sn, c12, c1;
+    azg_sincos(theta2, &sn2, &cs2);
+    azg_sincos((theta1 + theta2) - pi / 2.0, &sn, &c12);
+    azg_sincos(theta1 - pi / 2.0, &sn, &c1);
+    const double d1 = ((0.25 + (1.25 + cs2)) + 1.0) + 1.0;     /* m1 lc1^2 + m2 (l1^2 + lc2^2 + 2 l1 lc2 cos theta2) + I1 + I2 */
+    const double d2 = (0.25 + 0.5 * cs2) + 1.0;                /* m2 (lc2^2 + l1 lc2 cos theta2) + I2 */
+    const double phi2 = (0.5 * g) * c12;                       /* m2 lc2 g cos(theta1 + theta2 - pi / 2) */
+    const double phi1 = ((-(0.5 * (dtheta2 * dtheta2)) * sn2 - ((1.0 * dtheta2) * dtheta1) * sn2) + (1.5 * g) * c1) + phi2;
+    const double ddtheta2 = ((((a + (d2 / d1) * phi1) - (0.5 * (dtheta1 * dtheta1)) * sn2) - phi2)) / ((0.25 + 1.0) - (d2 * d2) / d1);
+    const double ddtheta1 = -((d2 * ddtheta2 + phi1)) / d1;
+    ds[0] = dtheta1; ds[1] = dtheta2; ds[2] = ddtheta1; ds[3] = ddtheta2;
+}
+
+/* AcrobotEnv.step: one classical Runge-Kutta step of dt = 0.2 (gym's rk4), angles wrapped into [-pi, pi], velocities bounded to
+ * +-4 pi / +-9 pi; terminal when the tip is above the line (-cos theta1 - cos(theta1 + theta2) > 1); reward -1, 0 on the terminal step. */
+AZG_HD void azg_acrobot_step(const double* s, int action, double* o, double* reward, int* done) {
+    const double pi = 3.141592653589793, dt = 0.2, dt2 = 0.1;
+    const double a = (double)(action - 1);
+    double k1[4], k2[4], k3[4], k4[4], y[4];
+    azg_acrobot_dsdt(s, a, k1);
+    AZG_UNROLL for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k1[i];
+    azg_acrobot_dsdt(y, a, k2);
+    AZG_UNROLL for (int i = 0; i < 4; ++i) y[i] = s[i] + dt2 * k2[i];
+    azg_acrobot_dsdt(y, a, k3);
+    AZG_UNROLL for (int i = 0; i < 4; ++i) y[i] = s[i] + dt * k3[i];
+    azg_acrobot_dsdt(y, a, k4);
+    AZG_UNROLL for (int i = 0; i < 4; ++i) o[i] = s[i] + (dt / 6.0) * (((k1[i] + 2.0 * k2[i]) + 2.0 * k3[i]) + k4[i]);
+    AZG_UNROLL for (int i = 0; i < 2; ++i) {   /* wrap(x, -pi, pi) */
+        double x = o[i];
+        for (int it = 0; it < 64 && x > pi; ++it) x = x - 2.0 * pi;
+        for (int it = 0; it < 64 && x < -pi; ++it) x = x + 2.0 * pi;
+        o[i] = x;
+    }
+    const double m1 = 4.0 * pi, m2 = 9.0 * pi;
+    o[2] = o[2] < -m1 ? -m1 : (o[2] > m1 ? m1 : o[2]);
+    o[3] = o[3] < -m2 ? -m2 : (o[3] > m2 ? m2 : o[3]);
+    double sn, c0, c01;
+    azg_sincos(o[0], &sn, &c0);
+    azg_sincos(o[1] + o[0], &sn, &c01);
+    const int d = (-c0 - c01) > 1.0;
+    *done = d;
+    *reward = d ? 0.0 : -1.0;
+}
+AZG_HD int azg_acrobot_terminal(const double* s) {
+    double sn, c0, c01;
+    azg_sincos(s[0], &sn, &c0);
+    azg_sincos(s[1] + s[0], &sn, &c01);
+    return (-c0 - c01) > 1.0;
+}
+AZG_HD void azg_acrobot_obs(const double* s, float* obs) {
+    double sn, cs;
+    azg_sincos(s[0], &sn, &cs);
+    obs[0] = (float)cs; obs[1] = (float)sn;
+    azg_sincos(s[1], &sn, &cs);
+    obs[2] = (float)cs; obs[3] = (float)sn;
+    obs[4] = (float)s[2]; obs[5] = (float)s[3];
+}
+
 /* uniform in (0,1) with 24 bits: (x>>8 + 0.5) * 2^-24 */
 AZG_HD float azg_u01(uint32_t x) {
     return AZG_FMAF((float)(x >> 8), 5.9604644775390625e-08f, 2.98023223876953125e-08f);
@@ -241,8 +307,11 @@ AZG_HD float azg_u01(uint32_t x) {
 #define AZG_RESET_PENDULUM 0
 #define AZG_RESET_CARTPOLE 1
 #define AZG_RESET_MOUNTAINCAR 2
+#define AZG_RESET_ACROBOT 3   /* all four state variables ~ U(-0.1, 0.1) */
 /* (both MountainCar envs start at position U(-0.6, -0.4) with velocity 0) */
-AZG_HD int azg_reset_kind(int env_id) { return env_id == 0 ? AZG_RESET_CARTPOLE : ((env_id == 3 || env_id == 4) ? AZG_RESET_MOUNTAINCAR : AZG_RESET_PENDULUM); }
+AZG_HD int azg_reset_kind(int env_id) {
+    return env_id == 0 ? AZG_RESET_CARTPOLE : ((env_id == 3 || env_id == 4) ? AZG_RESET_MOUNTAINCAR : (env_id == 5 ? AZG_RESET_ACROBOT : AZG_RESET_PENDULUM));
+}
 AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int kind, double* s);
 
 /* the engine's draw #`draw` of stream `stream` for (global tree id, search index) */
@@ -257,6 +326,8 @@ AZG_HD void azg_reset_state(uint64_t seed, uint32_t tree, uint32_t episode, int 
     for (int k = 0; k < 4; ++k) u[k] = ((double)b.v[k] + 0.5) * (1.0 / 4294967296.0);
     if (kind == AZG_RESET_CARTPOLE) {
         for (int k = 0; k < 4; ++k) s[k] = -0.05 + 0.1 * u[k];
+    } else if (kind == AZG_RESET_ACROBOT) {
+        for (int k = 0; k < 4; ++k) s[k] = -0.1 + 0.2 * u[k];
     } else if (kind == AZG_RESET_MOUNTAINCAR) {
         s[0] = -0.6 + 0.2 * u[0];
         s[1] = 0.0;

@@ -31,8 +31,10 @@ enum { AZG_OK = 0, AZG_E_INVALID = -1, AZG_E_TERMINAL_ROOT = -2, AZG_E_DEVICE = 
 
 /* closed-form environments (gym classic control; call sites alphazero/search/mcts.py:443-449, 680-687) */
 enum { AZG_ENV_CARTPOLE = 0, AZG_ENV_PENDULUM_V0 = 1, AZG_ENV_PENDULUM_V1 = 2, AZG_ENV_MOUNTAINCAR = 3,
-       AZG_ENV_MOUNTAINCAR_CONT = 4 /* gym MountainCarContinuous-v0: one continuous action, TERMINATES at the flag -- the
-                                       continuous search's terminal-node surface (mcts.py:599-600, 619-623, 682) */ };
+       AZG_ENV_MOUNTAINCAR_CONT = 4, /* gym MountainCarContinuous-v0: one continuous action, TERMINATES at the flag -- the
+                                        continuous search's terminal-node surface (mcts.py:599-600, 619-623, 682) */
+       AZG_ENV_ACROBOT = 5 /* gym Acrobot-v1: three discrete torques, SIX observations (the network's first layer takes two MFMA
+                              k-steps), reward -1 per step and 0 on the step that ends the episode */ };
 /* MCTSDiscrete (mcts.py:310-526) / MCTSContinuous (mcts.py:529-741) */
 enum { AZG_MODE_DISCRETE = 0, AZG_MODE_CONTINUOUS = 1 };
 /* V_target_policy (mcts.py:299-304) */
@@ -56,7 +58,7 @@ typedef struct azg_config {
     int32_t mode;          /* AZG_MODE_* */
     int32_t n_trees;       /* B: independent trees searched by one azg_search call */
     int32_t n_sims;        /* n_rollouts */
-    int32_t num_actions;   /* discrete only: the env's own action count (CartPole 2, MountainCar 3) */
+    int32_t num_actions;   /* discrete only: the env's own action count (CartPole 2, MountainCar 3, Acrobot 3) */
     int32_t v_target;      /* AZG_VT_* */
     int32_t tree_id_base;  /* global id of local tree 0 (multi-GPU sharding; keys the RNG streams) */
     int32_t tie_break;     /* AZG_TIE_* : what helpers.argmax (helpers.py:30-52) does with exactly equal scores */
@@ -111,7 +113,7 @@ int azg_set_search_index(azg_engine* e, uint32_t idx);
 
 /* MCTS*.search(Env) (mcts.py:418-462, 656-702) for B trees.
  *   root_env_state [B][S_env] float64: CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot); both MountainCars
- *                  (position, velocity)
+ *                  (position, velocity); Acrobot (theta1, theta2, theta1_dot, theta2_dot)
  *   root_n_carry   [B] or NULL: visit count carried by a reused root (MCTSDiscrete.forward, mcts.py:495-526)
  * Terminal roots -> AZG_E_TERMINAL_ROOT (ValueError at mcts.py:382-383, 599-600). */
 int azg_search(azg_engine* e, const double* root_env_state, const int32_t* root_n_carry);

@@ -124,13 +124,18 @@ const char* azo_last_error(const azg_engine* e) { return e ? e->err : g_create_e
 
 /* ------------------------------------------------------------------ environments (float64) */
 
-static int env_state_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : 2; }
-static int env_obs_dim(int env) { return env == AZG_ENV_CARTPOLE ? 4 : ((env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3); }
-static int env_is_discrete(int env) { return env == AZG_ENV_CARTPOLE || env == AZG_ENV_MOUNTAINCAR; }
-static int env_num_actions(int env) { return env == AZG_ENV_CARTPOLE ? 2 : (env == AZG_ENV_MOUNTAINCAR ? 3 : 0); }
+static int env_state_dim(int env) { return (env == AZG_ENV_CARTPOLE || env == AZG_ENV_ACROBOT) ? 4 : 2; }
+static int env_obs_dim(int env) {
+    if (env == AZG_ENV_ACROBOT) return 6;
+    return env == AZG_ENV_CARTPOLE ? 4 : ((env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_MOUNTAINCAR_CONT) ? 2 : 3);
+}
+static int env_is_discrete(int env) { return env == AZG_ENV_CARTPOLE || env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_ACROBOT; }
+static int env_num_actions(int env) { return env == AZG_ENV_CARTPOLE ? 2 : ((env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_ACROBOT) ? 3 : 0); }
 
 static void env_obs(int env, const double* s, float* obs) {
-    if (env == AZG_ENV_CARTPOLE) {
+    if (env == AZG_ENV_ACROBOT) {
+        azg_acrobot_obs(s, obs);   /* (cos, sin of both angles, both velocities: include/azg_math.h) */
+    } else if (env == AZG_ENV_CARTPOLE) {
         for (int i = 0; i < 4; ++i) obs[i] = (float)s[i];
     } else if (env == AZG_ENV_MOUNTAINCAR || env == AZG_ENV_MOUNTAINCAR_CONT) {
         obs[0] = (float)s[0]; obs[1] = (float)s[1];
@@ -234,6 +239,7 @@ static void pendulum_step(int v1, const double* s, float action, double* o, doub
 static int env_root_terminal(int env, const double* s) {
     if (env == AZG_ENV_MOUNTAINCAR) return s[0] >= 0.5 && s[1] >= 0.0;
     if (env == AZG_ENV_MOUNTAINCAR_CONT) return s[0] >= 0.45 && s[1] >= 0.0;
+    if (env == AZG_ENV_ACROBOT) return azg_acrobot_terminal(s);
     if (env != AZG_ENV_CARTPOLE) return 0;
     const double theta_thr = 12.0 * 2.0 * 3.141592653589793 / 360.0, x_thr = 2.4;
     return (s[0] < -x_thr) || (s[0] > x_thr) || (s[2] < -theta_thr) || (s[2] > theta_thr);
@@ -395,14 +401,14 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
     if (!cfg || !out) return fail(NULL, AZG_E_INVALID, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(azg_config)) return fail(NULL, AZG_E_INVALID, "azg_config size mismatch");
     if (cfg->n_trees < 1 || cfg->n_sims < 1) return fail(NULL, AZG_E_INVALID, "n_trees and n_sims must be >= 1");
-    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_MOUNTAINCAR_CONT) return fail(NULL, AZG_E_INVALID, "unknown env_id");
+    if (cfg->env_id < 0 || cfg->env_id > AZG_ENV_ACROBOT) return fail(NULL, AZG_E_INVALID, "unknown env_id");
     if (cfg->mode == AZG_MODE_DISCRETE && !env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "discrete mode requires a discrete-action env (CartPole)");
     if (cfg->mode == AZG_MODE_CONTINUOUS && env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
     if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(NULL, AZG_E_INVALID, "unknown tie_break");
     if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != env_num_actions(cfg->env_id))
-        return fail(NULL, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3)");
+        return fail(NULL, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3, Acrobot 3)");
     azg_engine* e = (azg_engine*)calloc(1, sizeof(azg_engine));
     e->cfg = *cfg;
     e->S_env = env_state_dim(cfg->env_id);
@@ -685,6 +691,7 @@ static void search_tree(ctx_t* c, const double* root, int carry) {
             const double* s = t->state + (size_t)node * e->S_env;
             if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(s, (int)t->edge_action[k], ns, &r, &done);
             else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(s, (int)t->edge_action[k], ns, &r, &done);
+            else if (e->cfg.env_id == AZG_ENV_ACROBOT) azg_acrobot_step(s, (int)t->edge_action[k], ns, &r, &done);
             else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(s, t->edge_action[k], ns, &r, &done);
             else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, s, t->edge_action[k], ns, &r, &done);
             if (e->cfg.mode == AZG_MODE_CONTINUOUS) r = r / e->cfg.reward_scale;   /* mcts.py:687 */
@@ -981,6 +988,7 @@ int azo_selfplay_step(azg_engine* e) {
         int done;
         if (e->cfg.env_id == AZG_ENV_CARTPOLE) cartpole_step(root, pick, ns, &r, &done);
         else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(root, pick, ns, &r, &done);
+        else if (e->cfg.env_id == AZG_ENV_ACROBOT) azg_acrobot_step(root, pick, ns, &r, &done);
         else if (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(root, t->edge_action[krec], ns, &r, &done);
         else pendulum_step(e->cfg.env_id == AZG_ENV_PENDULUM_V1, root, t->edge_action[krec], ns, &r, &done);
         e->sp_ret[i] = e->sp_ret[i] + r;
@@ -1131,6 +1139,7 @@ int azo_env_step(int env_id, const double* state, float action, double* next, do
     int d = 0;
     if (env_id == AZG_ENV_CARTPOLE) cartpole_step(state, (int)action, next, reward, &d);
     else if (env_id == AZG_ENV_MOUNTAINCAR) mountaincar_step(state, (int)action, next, reward, &d);
+    else if (env_id == AZG_ENV_ACROBOT) azg_acrobot_step(state, (int)action, next, reward, &d);
     else if (env_id == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(state, action, next, reward, &d);
     else if (env_id == AZG_ENV_PENDULUM_V0 || env_id == AZG_ENV_PENDULUM_V1) pendulum_step(env_id == AZG_ENV_PENDULUM_V1, state, action, next, reward, &d);
     else return AZG_E_INVALID;

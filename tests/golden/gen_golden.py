@@ -74,7 +74,7 @@ from alphazero.network.policies import make_policy  # noqa: E402
 
 import oracle_lib as O  # noqa: E402
 from alphazero_gym_amd import _capi  # noqa: E402
-from alphazero_gym_amd.envs import CartPoleEnv, MountainCarContinuousEnv, MountainCarEnv, PendulumEnv  # noqa: E402
+from alphazero_gym_amd.envs import AcrobotEnv, CartPoleEnv, MountainCarContinuousEnv, MountainCarEnv, PendulumEnv  # noqa: E402
 
 torch.set_num_threads(1)
 TIES = {"n": 0}
@@ -198,7 +198,7 @@ def dump_reference_tree(root, R):
 def run_t1(case):
     """One T1 case: several independent trees, one reference MCTS object per tree."""
     cont = case["mode"] == 1
-    in_dim = (2 if case["env_id"] == 4 else 3) if cont else (2 if case["env_id"] == 3 else 4)
+    in_dim = (2 if case["env_id"] == 4 else 3) if cont else {3: 2, 5: 6}.get(case["env_id"], 4)
     n_dist = 2 if cont else case["num_actions"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
                          gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0),
@@ -219,6 +219,9 @@ def run_t1(case):
         elif cont:
             env = PendulumEnv(state=root, version=1 if case["env_id"] == 2 else 0)
             root_obs = env._get_obs()
+        elif case["env_id"] == 5:
+            env = AcrobotEnv(state=root)                    # six observations, reward 0 on the terminal step
+            root_obs = env._get_ob()
         else:
             env = MountainCarEnv(state=root) if case["env_id"] == 3 else CartPoleEnv(state=root)
             root_obs = np.array(env.state, dtype=np.float32)
@@ -313,6 +316,14 @@ T1_CASES = {
     "t1_mcc_terminal_eps": dict(env_id=4, mode=1, n_sims=90, c_uct=0.3, c_pw=0.9, kappa=0.65, gamma=0.97, epsilon=0.2,
                                 v_target="on_policy", hidden=[128, 128], act="relu", wseed=42, seed=44, wscale=3.0, action_bound=1.0,
                                 tree_id_base=300, search_idx=2, roots=[[0.40, 0.045], [0.34, 0.06], [0.25, 0.065]]),
+    # gym Acrobot-v1: six observations (two k-steps in the network's first layer), three torques, Runge-Kutta dynamics, reward -1 per step
+    # and 0 on the step that ends the episode; roots about to swing the tip over the line (terminal children), at rest, on the way up
+    "t1_acrobot_default": dict(env_id=5, mode=0, num_actions=3, n_sims=70, c_uct=1.0, gamma=0.99, epsilon=0.0, v_target="off_policy",
+                               hidden=[64, 64], act="relu", wseed=51, seed=53, wscale=2.0,
+                               roots=[[1.9, 0.2, 2.0, 1.0], [0.05, -0.03, 0.02, 0.01], [1.373, -0.681, 2.48, 1.698], [-1.852, 0.74, -1.543, -1.538]]),
+    "t1_acrobot_epsgreedy_reuse": dict(env_id=5, mode=0, num_actions=3, n_sims=40, c_uct=2.5, gamma=1, epsilon=0.15, v_target="on_policy",
+                                       hidden=[128, 128], act="elu", wseed=52, seed=54, wscale=3.0, reuse_steps=3, tree_id_base=40,
+                                       roots=[[1.373, -0.681, 2.48, 1.698], [-0.4, 0.6, 1.0, -1.0]]),
     "t1_mountaincar_epsgreedy_reuse": dict(env_id=3, mode=0, num_actions=3, n_sims=40, c_uct=2.0, gamma=1, epsilon=0.15,
                                            v_target="on_policy", hidden=[128, 128], act="elu", wseed=19, seed=22, wscale=3.0,
                                            reuse_steps=3, roots=[[-0.45, 0.01], [0.41, 0.04]]),
@@ -613,8 +624,9 @@ def _t3_scale_chunk(job):
     reference's DiagonalNormalPolicy; 'b': CartPole discrete with its DiscretePolicy)."""
     kind, hidden, n_rollouts, lo, hi, roots, seed = job
     torch.set_num_threads(1)
-    cont = kind not in ("b", "d", "m")
+    cont = kind not in ("b", "d", "m", "a")
     car = kind == "m"           # gym MountainCar-v0: three actions, observation = (position, velocity)
+    acro = kind == "a"          # gym Acrobot-v1: three actions, six observations
     mcc = kind == "h"           # gym MountainCarContinuous-v0: continuous search with terminal nodes (VERDICT r04 row h)
     gmm = kind == "g"           # the reference's default continuous policy: 2-component mixture (config/policy/ContinuousPolicy.yaml)
     eps = 0.1 if kind == "d" else 0.0   # the reference's default discrete search: epsilon-greedy 0.1 (config/mcts/MCTSDiscrete.yaml)
@@ -638,6 +650,11 @@ def _t3_scale_chunk(job):
         pol = make_policy(representation_dim=2, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
                           num_actions=3)
         set_policy_weights(pol, blob, 2, hidden, 3)
+    elif acro:
+        blob = O.make_weights(34, 6, hidden, 3)
+        pol = make_policy(representation_dim=6, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
+                          num_actions=3)
+        set_policy_weights(pol, blob, 6, hidden, 3)
     else:
         blob = O.make_weights(34, 4, hidden, 2)
         pol = make_policy(representation_dim=4, action_dim=1, distribution="discrete", hidden_dimensions=hidden, nonlinearity="relu",
@@ -687,6 +704,10 @@ def _t3_scale_chunk(job):
                 env = MountainCarEnv(state=roots[ti - lo])
                 m = RM.MCTSDiscrete(model=pol, num_actions=3, n_rollouts=n_rollouts, c_uct=0.8, gamma=0.99, epsilon=0.0,
                                     V_target_policy="off_policy", device="cpu", root_state=np.array(env.state, dtype=np.float32))
+            elif acro:
+                env = AcrobotEnv(state=roots[ti - lo])
+                m = RM.MCTSDiscrete(model=pol, num_actions=3, n_rollouts=n_rollouts, c_uct=0.8, gamma=0.99, epsilon=0.0,
+                                    V_target_policy="off_policy", device="cpu", root_state=env._get_ob())
             else:
                 env = CartPoleEnv(state=roots[ti - lo])
                 m = RM.MCTSDiscrete(model=pol, num_actions=2, n_rollouts=n_rollouts, c_uct=1.5, gamma=1, epsilon=eps,
@@ -715,7 +736,17 @@ T3_SCALE = {   # tag: (env_id, mode, hidden, activation, n_rollouts, trees, engi
     # the continuous search over an env whose episodes end (mcts.py:619-623, 682): gym MountainCarContinuous-v0 with the reference's
     # DiagonalNormalPolicy (2x256 ELU, action bound 1), 120 rollouts, roots on the slope below the flag (mcc_scale_roots)
     "h": (4, 1, [256, 256], "elu", 120, 1024, dict(c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, action_bound=1.0)),
+    # six observations end to end: gym Acrobot-v1 with the reference's DiscretePolicy (2x64 ReLU), 50 rollouts, roots on the way up (acrobot_scale_roots)
+    "a": (5, 0, [64, 64], "relu", 50, 1024, dict(c_uct=0.8, gamma=0.99, num_actions=3)),
 }
+
+
+def acrobot_scale_roots(synthetic):
+    """Roots of the Acrobot leg: the engine's synthetic roots hang at rest (all four variables U(-0.1, 0.1)), hundreds of steps from the
+    episode's end.  They are mapped onto the upswing: theta1 = 1.4 + 6 s0, theta2 = 8 s1, dtheta1 = 3 + 20 s2, dtheta2 = 20 s3 -- from
+    a step to many steps below the line the tip has to cross (the same formula in tests/test_t3_scale.py)."""
+    s = np.asarray(synthetic)
+    return np.stack([1.4 + 6.0 * s[:, 0], 8.0 * s[:, 1], 3.0 + 20.0 * s[:, 2], 20.0 * s[:, 3]], 1)
 
 
 def mcc_scale_roots(synthetic):
@@ -744,8 +775,12 @@ def run_t3_scale(procs=8, only=None):
         roots = eng.synthetic_roots()
         if tag == "h":
             roots = mcc_scale_roots(roots)
-        n_dist = 6 if tag == "g" else (3 if tag == "m" else 2)
-        in_dim = 2 if tag in ("m", "h") else (4 if mode == 0 else 3)
+        if tag == "a":
+            roots = acrobot_scale_roots(roots)
+            keep = np.array([not AcrobotEnv(state=r)._terminal() for r in roots])
+            roots[~keep] = [1.0, 0.0, 0.5, 0.0]            # (a mapped root that is already above the line: replaced by a fixed one)
+        n_dist = 6 if tag == "g" else (3 if tag in ("m", "a") else 2)
+        in_dim = 6 if tag == "a" else (2 if tag in ("m", "h") else (4 if mode == 0 else 3))
         eng.set_weights(_capi.make_desc(in_dim, hidden, n_dist, act, num_components=2 if tag == "g" else 0),
                         O.make_weights(35 if tag == "g" else 34, in_dim, hidden, n_dist))
         eng.trace_enable()
@@ -1033,6 +1068,10 @@ T7_CASES = {
     "mcc": dict(env_id=4, mode=1, n_sims=24, c_uct=0.05, c_pw=1, kappa=0.5, gamma=1, epsilon=0.0, v_target="off_policy",
                 hidden=[64, 64], act="elu", wseed=10, wscale=2.0, seed=18, tree_id_base=7, n_games=4, n_steps=10, max_len=6,
                 action_bound=1.0, first_roots=[[0.41, 0.04], [0.33, 0.06], [0.36, 0.02], [-0.5, 0.0]]),
+    # Acrobot-v1: games start on the upswing (first_roots), so that episodes END by the tip crossing the line (reward 0 on that step)
+    "acrobot_sampled": dict(env_id=5, mode=0, num_actions=3, n_sims=16, c_uct=2.0, gamma=0.98, epsilon=0.0, v_target="off_policy",
+                            hidden=[64, 64], act="relu", wseed=11, wscale=3.0, seed=19, tree_id_base=4, n_games=3, n_steps=12, max_len=6,
+                            det=False, first_roots=[[1.9, 0.2, 2.0, 1.0], [1.373, -0.681, 2.48, 1.698], [0.05, -0.03, 0.02, 0.01]]),
     "mountaincar_sampled": dict(env_id=3, mode=0, num_actions=3, n_sims=18, c_uct=2.0, gamma=0.98, epsilon=0.0, v_target="off_policy",
                                 hidden=[64, 64], act="relu", wseed=9, wscale=3.0, seed=17, tree_id_base=3, n_games=3, n_steps=16, max_len=7,
                                 det=False),
@@ -1049,7 +1088,8 @@ def run_t7(case):
     cont = case["mode"] == 1
     mcc = case["env_id"] == 4
     bound = case.get("action_bound", 2.0)
-    in_dim = (2 if mcc else 3) if cont else (2 if case["env_id"] == 3 else 4)
+    in_dim = (2 if mcc else 3) if cont else {3: 2, 5: 6}.get(case["env_id"], 4)
+    acro = case["env_id"] == 5
     n_dist = 2 if cont else case["num_actions"]
     seed = case["seed"]
     eng = O.OracleEngine(env_id=case["env_id"], mode=case["mode"], n_trees=1, n_sims=case["n_sims"], c_uct=case["c_uct"],
@@ -1100,7 +1140,7 @@ def run_t7(case):
                                             kappa=case["kappa"], gamma=case["gamma"], epsilon=case["epsilon"],
                                             V_target_policy=case["v_target"], device="cpu", root_state=None)
             else:
-                env = MountainCarEnv() if case["env_id"] == 3 else CartPoleEnv()
+                env = AcrobotEnv() if acro else (MountainCarEnv() if case["env_id"] == 3 else CartPoleEnv())
                 ag = object.__new__(RA.DiscreteAgent)
                 ag.final_selection = fs; ag.temperature = case.get("temperature", 1.0)
                 ag.mcts = RM.MCTSDiscrete(model=None, num_actions=case["num_actions"], n_rollouts=case["n_sims"], c_uct=case["c_uct"],
@@ -1114,7 +1154,7 @@ def run_t7(case):
                 if episode == 0 and "first_roots" in case:
                     rs = np.asarray(case["first_roots"][g], np.float64)   # (the test uploads these roots after selfplay_begin)
                 env.state = np.asarray(rs, np.float64) if cont else tuple(float(v) for v in rs)
-                state = (np.array(env.state) if mcc else env._get_obs()) if cont else np.array(env.state, dtype=np.float32)
+                state = (np.array(env.state) if mcc else env._get_obs()) if cont else (env._get_ob() if acro else np.array(env.state, dtype=np.float32))
                 R = 0.0
                 ag.reset_mcts(root_state=state)
                 for t in range(max_len):

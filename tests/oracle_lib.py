@@ -106,9 +106,9 @@ def reset_state(seed, tree, episode, cartpole, env_id=None):
     """A self-play game's initial state of an episode (the engine's stand-in for Env.reset()).  env_id (optional) selects the
     env's reset law; without it: CartPole if `cartpole` else Pendulum."""
     out = np.zeros(4, np.float64)
-    kind = (1 if cartpole else 0) if env_id is None else {0: 1, 3: 2, 4: 2}.get(env_id, 0)   # include/azg_math.h: AZG_RESET_*
+    kind = (1 if cartpole else 0) if env_id is None else {0: 1, 3: 2, 4: 2, 5: 3}.get(env_id, 0)   # include/azg_math.h: AZG_RESET_*
     lib().azo_reset_state(seed, tree, episode, kind, _capi._ptr(out, C.c_double))
-    return out[:4 if kind == 1 else 2].copy()
+    return out[:4 if kind in (1, 3) else 2].copy()
 
 
 def act_draw(seed, tree, step):
@@ -135,7 +135,7 @@ def env_step(env_id, state, action):
     nxt = np.empty_like(state)
     r = C.c_double()
     d = C.c_int32()
-    obs = np.empty(({0: 4, 3: 2, 4: 2}.get(env_id, 3),), np.float32)
+    obs = np.empty(({0: 4, 3: 2, 4: 2, 5: 6}.get(env_id, 3),), np.float32)
     rc = lib().azo_env_step(env_id, _capi._ptr(state, C.c_double), float(action), _capi._ptr(nxt, C.c_double), C.byref(r),
                             C.byref(d), _capi._ptr(obs, C.c_float))
     assert rc == 0

@@ -13,6 +13,7 @@ T1_NAMES = [
     "t1_pendulum_v1_default", "t1_pendulum_v0_gamma", "t1_pendulum_v1_epsgreedy", "t1_cartpole_default",
     "t1_cartpole_epsgreedy", "t1_cartpole_explore", "t1_cartpole_reuse", "t1_mountaincar_default", "t1_mountaincar_epsgreedy_reuse",
     "t1_mcc_terminal", "t1_mcc_terminal_eps",   # MCTSContinuous with terminal nodes (MountainCarContinuous-v0; mcts.py:619-623, 682)
+    "t1_acrobot_default", "t1_acrobot_epsgreedy_reuse",   # six observations, reward 0 on the terminal step (Acrobot-v1)
 ]
 
 DUMP_INT = ("n_records", "parent", "edge_n", "node_n", "node_flags")
@@ -35,7 +36,7 @@ def engine_kwargs(case, n_trees, tree_id_base=None):
 
 def case_weights(case):
     cont = case["mode"] == 1
-    in_dim = (2 if case["env_id"] == 4 else 3) if cont else (2 if case["env_id"] == 3 else 4)
+    in_dim = (2 if case["env_id"] == 4 else 3) if cont else {3: 2, 5: 6}.get(case["env_id"], 4)
     n_dist = 2 if cont else case["num_actions"]
     blob = O.make_weights(case["wseed"], in_dim, case["hidden"], n_dist, scale=case.get("wscale", 1.0))
     return _capi.make_desc(in_dim, case["hidden"], n_dist, case["act"]), blob

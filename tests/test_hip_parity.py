@@ -153,7 +153,21 @@ CONFIGS = [
     (4, 1, [512, 512], "elu", 30, dict(c_uct=0.05, gamma=1.0, action_bound=1.0)),
     (4, 1, [64, 64], "relu", 300, dict(c_uct=0.05, gamma=0.99, action_bound=1.0)),
     (4, 1, [128, 128], "elu", 90, dict(c_uct=0.2, gamma=1.0, c_pw=2.0, kappa=0.6, action_bound=1.0, v_target="greedy")),
+    # six observations (gym Acrobot-v1): two k-steps in the network's first layer, Runge-Kutta dynamics, reward 0 on the terminal step --
+    # LDS trees of 8- and 9-bit ids, global trees, epsilon-greedy, 2x256 and a wide network (one-launch kernel: the team kernels take
+    # at most four inputs), LayerNorm (weight-streaming kernels)
+    (5, 0, [64, 64], "relu", 60, dict(c_uct=1.0, gamma=0.99, num_actions=3)),
+    (5, 0, [128, 128], "elu", 120, dict(c_uct=2.0, gamma=1.0, num_actions=3, epsilon=0.2, v_target="on_policy")),
+    (5, 0, [256, 256], "relu", 50, dict(c_uct=1.5, gamma=0.97, num_actions=3)),
+    (5, 0, [512, 512], "relu", 20, dict(c_uct=1.5, gamma=1.0, num_actions=3)),
+    (5, 0, [64], "relu", 200, dict(c_uct=3.0, gamma=0.98, num_actions=3, v_target="greedy")),
+    (5, 0, [100, 60], "silu", 30, dict(c_uct=2.0, gamma=1.0, num_actions=3, _ln=True)),
 ]
+
+
+def upswing_roots(roots):
+    """Acrobot roots on the upswing (the synthetic ones hang at rest, hundreds of steps from the episode's end)."""
+    return np.stack([1.4 + 6.0 * roots[:, 0], 8.0 * roots[:, 1], 3.0 + 20.0 * roots[:, 2], 20.0 * roots[:, 3]], 1)
 
 
 def slope_roots(roots):
@@ -192,7 +206,7 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     if variant == "no_spec":
         # register-resident one-layer networks with common parameters run kernels specialised at compile time (dispatch.cuh: SPEC);
         # this variant forces the general kernels on the same inputs
-        if len(hidden) != 2 or max(hidden) > 256 or ln or ncomp or extra.get("epsilon", 0.0) != 0.0 or n_sims > 126 or env == 3:
+        if len(hidden) != 2 or max(hidden) > 256 or ln or ncomp or extra.get("epsilon", 0.0) != 0.0 or n_sims > 126 or env in (3, 5):
             pytest.skip("no compile-time specialised kernel exists for this configuration")
         monkeypatch.setenv("AZG_NO_SPEC", "1")
     if variant == "tile16":
@@ -208,7 +222,7 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
             monkeypatch.setenv("AZG_LS_TEAM", "0")            # the per-layer launches instead of the persistent team kernel
     B = 37
     kw = dict(env_id=env, mode=mode, n_trees=B, n_sims=n_sims, seed=1234, tree_id_base=77, **extra)
-    in_dim, n_dist = (2 if env == 4 else 3, 3 * ncomp if ncomp else 2) if mode == 1 else ((2, 3) if env == 3 else (4, 2))
+    in_dim, n_dist = (2 if env == 4 else 3, 3 * ncomp if ncomp else 2) if mode == 1 else {3: (2, 3), 5: (6, 3)}.get(env, (4, 2))
     desc = _capi.make_desc(in_dim, hidden, n_dist, act, num_components=ncomp, layernorm=ln)
     blob = O.make_weights(99, in_dim, hidden, n_dist, scale=2.0)
     if ln:
@@ -222,6 +236,14 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     if env == 3:
         roots[3] = [0.44, 0.04]               # the flag is two steps away
         roots[5] = [-1.195, -0.05]            # into the left wall
+    if env == 5:
+        roots = upswing_roots(roots)
+        for i in range(B):
+            if O.env_step(5, roots[i], 1)[2] and (-np.cos(roots[i][0]) - np.cos(roots[i][1] + roots[i][0])) > 1.0:
+                roots[i] = [1.0, 0.0, 0.5, 0.0]           # (already above the line)
+        roots[3] = [1.9, 0.2, 2.0, 1.0]           # every torque swings the tip over the line: terminal children, reward 0
+        roots[5] = [1.373, -0.681, 2.48, 1.698]   # three steps below it
+        roots[7] = [0.05, -0.03, 0.02, 0.01]      # hanging at rest
     if env == 4:
         roots = slope_roots(roots)
         roots[3] = [0.44, 0.03]               # every action reaches the flag: a search of traces that end in terminal nodes
@@ -560,8 +582,11 @@ def _random_case(rng):
     elif rng.random() < 0.65:
         env, mode, in_dim, n_dist = 0, 0, 4, 2
         extra.update(c_uct=float(rng.choice([1.5, 5.0, 30.0])), num_actions=2)
-    else:   # three actions (gym MountainCar-v0)
+    elif rng.random() < 0.5:   # three actions (gym MountainCar-v0)
         env, mode, in_dim, n_dist = 3, 0, 2, 3
+        extra.update(c_uct=float(rng.choice([0.8, 2.0, 6.0])), num_actions=3)
+    else:   # three actions, six observations (gym Acrobot-v1)
+        env, mode, in_dim, n_dist = 5, 0, 6, 3
         extra.update(c_uct=float(rng.choice([0.8, 2.0, 6.0])), num_actions=3)
     if mode == 0 and rng.random() < 0.2:
         extra["tie_break"] = "random"
@@ -599,6 +624,11 @@ def test_hip_bit_exact_vs_oracle_random_configurations(native, seed):
     o.close()
     if env == 4:
         roots = slope_roots(roots)
+    if env == 5:
+        roots = upswing_roots(roots)
+        for i in range(B):
+            if (-np.cos(roots[i][0]) - np.cos(roots[i][1] + roots[i][0])) > 0.98:
+                roots[i] = [1.0, 0.0, 0.5, 0.0]
     carry = np.minimum(np.arange(B) % 5, 3 * n_sims).astype(np.int32) if mode == 0 else None
     sidx = int(rng.integers(0, 50))
     a = _run(native.HipEngine, kw, desc, blob, roots, carry, sidx=sidx)

@@ -141,6 +141,34 @@ def test_mountaincar_continuous_c_env_matches_python_env():
         assert -0.6 <= s[0] <= -0.4 and s[1] == 0.0
 
 
+def test_acrobot_c_env_matches_python_env():
+    """gym Acrobot-v1: the oracle's step (include/azg_math.h: one classical Runge-Kutta step of the "book" dynamics, angle wrap, velocity
+    bounds) against the Python restatement over the whole state space, all three torques, both sides of the terminal line; the
+    observation is (cos, sin) of both angles + both velocities; reward -1, 0 on the step that ends the episode."""
+    from alphazero_gym_amd.envs import AcrobotEnv
+    rng = np.random.Generator(np.random.PCG64(7))
+    n_done = n_wrap = 0
+    for i in range(1500):
+        s = np.array([rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi), rng.uniform(-4 * np.pi, 4 * np.pi), rng.uniform(-9 * np.pi, 9 * np.pi)])
+        if i % 3 == 0:
+            s[2:] *= 0.1                                              # (slow states: no wrap, no velocity bound)
+        a = int(rng.integers(0, 3))
+        e = AcrobotEnv(state=s)
+        obs, r, done, _ = e.step(a)
+        nxt, rc, dc, obsc = O.env_step(5, s, a)
+        # (the Runge-Kutta step amplifies the <= 1 ulp differences between azg_sincos and libm at high angular velocities)
+        np.testing.assert_allclose(nxt, e.state, rtol=0, atol=5e-13)
+        assert rc == r == (0.0 if done else -1.0) and dc == done
+        np.testing.assert_allclose(obsc, obs.astype(np.float32), rtol=0, atol=2e-7)
+        assert obsc.shape == (6,)
+        n_done += done
+        n_wrap += abs(s[0] + 0.2 * s[2]) > np.pi
+    assert n_done > 100 and n_wrap > 50
+    for ep in range(5):
+        s = O.reset_state(9, 3, ep, False, env_id=5)
+        assert s.shape == (4,) and (np.abs(s) <= 0.1).all()
+
+
 def test_hip_library_exports_every_symbol_of_the_header():
     """The drop-in boundary: every entry point declared in include/azgym.h must be exported by libazgym_hip.so
     (loading needs no GPU; no compute is called)."""

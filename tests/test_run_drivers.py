@@ -123,6 +123,38 @@ def test_device_selfplay_on_mountaincar_continuous(backend):
     assert hs.collect(4).shape == (20, 2 + 3 * K + 1) and len(hs.finished_returns) == 5
 
 
+def test_acrobot_through_the_discrete_surface(backend):
+    """`game: Acrobot-v1` through run_discrete.py's loop and DeviceSelfPlay: six observations (a second k-step in the network's first
+    layer), three torques, reward -1 per step; a DiscreteAgent.act on a state whose every torque swings the tip over the line searches a
+    tree of terminal children worth 0 (gym: `reward = -1. if not terminal else 0.`)."""
+    from alphazero_gym_amd.agent.agents import DiscreteAgent
+    from alphazero_gym_amd.agent.losses import AlphaZeroLoss
+    from alphazero_gym_amd.envs import AcrobotEnv
+    torch.manual_seed(0)
+    rets = run.run_discrete_agent(dict(game="Acrobot-v1", num_train_episodes=2, max_episode_length=5, mcts=dict(n_rollouts=8),
+                                       policy=dict(hidden_dimensions=[64]), buffer=dict(max_size=50, batch_size=4)))
+    assert rets == [-5.0, -5.0]                                   # hanging at rest: five steps of -1
+    pol = make_policy(representation_dim=6, action_dim=1, distribution="discrete", hidden_dimensions=[64, 64], nonlinearity="relu", num_actions=3)
+    env = AcrobotEnv(state=[1.9, 0.2, 2.0, 1.0])
+    mcts = dict(_target_="alphazero_gym_amd.search.mcts.MCTSDiscrete", num_actions=3, n_rollouts=30, c_uct=1.5, gamma=1.0, epsilon=0.0,
+                V_target_policy="off_policy", device="cpu", root_state=env._get_ob())
+    ag = DiscreteAgent(policy_cfg=pol, mcts_cfg=mcts, loss_cfg=AlphaZeroLoss(1.0, 1.0, "mean"), optimizer_cfg=dict(_target_="torch.optim.Adam", lr=1e-3),
+                       final_selection="max_visits", train_epochs=1, grad_clip=0, temperature=1.0, device="cpu")
+    action, s, actions, counts, Qs, V = ag.act(env, deterministic=True)
+    assert counts.sum() == 30 and len(counts) == 3
+    visited = counts > 1                                          # (an edge visited more than once: its Q is the mean of terminal returns)
+    np.testing.assert_array_equal(Qs[visited], 0.0)               # every child is terminal: return 0 + gamma * 0
+    _, r, done, _ = env.step(int(action))
+    assert done and r == 0.0
+    sp = run.DeviceSelfPlay(pol, game="Acrobot-v1", n_games=6, n_rollouts=16, c_uct=1.5, max_episode_length=4, capacity_steps=5)
+    rows = sp.collect(5)
+    assert rows.shape == (30, 6 + 3 * 3 + 1)
+    s_, a_, c_, q_, v_ = D.unpack_replay_rows(rows, 6, 3)
+    np.testing.assert_array_equal(c_.sum(1), np.full(30, 16.0))
+    np.testing.assert_allclose(np.hypot(s_[:, 0], s_[:, 1]), 1.0, atol=1e-6)    # (cos, sin) of theta1
+    np.testing.assert_allclose(np.hypot(s_[:, 2], s_[:, 3]), 1.0, atol=1e-6)    # (cos, sin) of theta2
+
+
 def test_device_selfplay_with_three_actions(backend):
     """MountainCar-v0 (three actions) through the device-resident self-play driver and one A0C training round."""
     from alphazero_gym_amd.agent.agents import DiscreteAgent

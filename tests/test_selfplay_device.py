@@ -129,7 +129,7 @@ def _engine_cls(which):
 
 def _t7_engine(cls, case, **over):
     cont = case["mode"] == 1
-    in_dim, n_dist = (2 if case["env_id"] == 4 else 3, 2) if cont else (2 if case["env_id"] == 3 else 4, case["num_actions"])
+    in_dim, n_dist = (2 if case["env_id"] == 4 else 3, 2) if cont else ({3: 2, 5: 6}.get(case["env_id"], 4), case["num_actions"])
     e = cls(env_id=case["env_id"], mode=case["mode"], n_trees=case["n_games"], n_sims=case["n_sims"], c_uct=case["c_uct"],
             gamma=case["gamma"], epsilon=case["epsilon"], num_actions=case.get("num_actions", 0), c_pw=case.get("c_pw", 1.0),
             kappa=case.get("kappa", 0.5), v_target=case["v_target"], seed=case["seed"], tree_id_base=case["tree_id_base"],
@@ -171,7 +171,7 @@ def test_selfplay_matches_the_reference_run_loop(name, which):
     want = z["rows"]
     np.testing.assert_array_equal(rows[..., So + K:So + 2 * K], want[..., So + K:So + 2 * K])    # visit counts
     np.testing.assert_array_equal(rows[..., So:So + K], want[..., So:So + K].astype(np.float32))  # root actions
-    np.testing.assert_allclose(rows[..., :So], want[..., :So], rtol=0, atol=1.2e-7)              # observation (float32)
+    np.testing.assert_allclose(rows[..., :So], want[..., :So], rtol=6e-8, atol=1.2e-7)           # observation (float32 rounding of the float64 value)
     np.testing.assert_allclose(rows[..., So + 2 * K:], want[..., So + 2 * K:], rtol=2e-7, atol=1e-7)   # Q and the value target
     np.testing.assert_array_equal(fcnt, z["fcnt"])
     np.testing.assert_allclose(fsum, z["fsum"], rtol=1e-12, atol=1e-12)
@@ -180,8 +180,8 @@ def test_selfplay_matches_the_reference_run_loop(name, which):
     if case["mode"] == 0:
         for s_ in range(1, n_steps):
             for g in range(G):
-                if z["carry_in"][s_, g] > 0:
-                    assert abs(z["root_before"][s_, g] - z["root_before"][s_ - 1, g]).max() < 1.0
+                if z["carry_in"][s_, g] > 0:   # (one env step apart; Acrobot's velocities move by more than 1 in a 0.2 s step)
+                    assert abs(z["root_before"][s_, g] - z["root_before"][s_ - 1, g]).max() < (8.0 if case["env_id"] == 5 else 1.0)
 
 
 @pytest.mark.parametrize("which", ENGINES)

@@ -1,12 +1,12 @@
 """Tier T3 at BASELINE scale (VERDICT r03 row g): visit-count parity with the reference run END TO END -- the reference's
 MCTSContinuous.search / MCTSDiscrete.search (alphazero/search/mcts.py:418-462, 656-702) with its REAL torch policies
 (alphazero/network/policies.py:340-352, 436-499) -- on the engine's own synthetic roots of configs C (all 4096 trees, 2x256 ELU,
-200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (512 trees, 4x1024 ELU, 200 rollouts), and -- 1024 trees
+200 rollouts), B (all 4096 trees, CartPole 2x128 ReLU, 100 rollouts) and E (all 1024 trees of the per-GPU leg, 4x1024 ELU, 200 rollouts), and -- 1024 trees
 each -- of the reference's own DEFAULT configurations (config/mcts/*.yaml, config/policy/*.yaml): the 2-component mixture head on a
 3x128 ELU trunk with 25 rollouts, and CartPole with 8 rollouts and epsilon-greedy 0.1 (the engine's draws injected as `random`);
 and 1024 trees of gym MountainCar-v0 (three actions) with the reference's DiscretePolicy; and 1024 trees of gym
 MountainCarContinuous-v0 -- the continuous search over an env whose episodes end (terminal nodes: mcts.py:619-623, 682) -- with the
-reference's DiagonalNormalPolicy:
+reference's DiagonalNormalPolicy; and 1024 trees of gym Acrobot-v1 (six observations) with its DiscretePolicy:
 tests/golden/t3_scale.npz, written by tests/golden/gen_golden.py `scale` from the imported reference.
 
 The networks differ from torch's by ~1e-7 (summation order), so a selection whose two best scores are closer than that could
@@ -40,8 +40,23 @@ LEGS = {   # tag: (engine kwargs, in_dim, hidden, activation, n_sims, network ou
     # the continuous search over an env whose episodes END (VERDICT r04 row h; mcts.py:619-623, 682): gym MountainCarContinuous-v0 with
     # the reference's DiagonalNormalPolicy (2x256 ELU, action bound 1), 120 rollouts, roots on the slope below the flag
     "h": (dict(env_id=4, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, action_bound=1.0, seed=34), 2, [256, 256], "elu", 120, 2, 0, 34),
+    # six observations end to end: gym Acrobot-v1 with the reference's DiscretePolicy (2x64 ReLU), 50 rollouts, roots on the upswing
+    "a": (dict(env_id=5, mode=0, c_uct=0.8, gamma=0.99, num_actions=3, seed=34), 6, [64, 64], "relu", 50, 3, 0, 34),
 }
-N_TREES_ALL = 4096 + 4096 + 512 + 1024 + 1024 + 1024 + 1024
+N_TREES_ALL = 4096 + 4096 + 1024 + 1024 + 1024 + 1024 + 1024 + 1024
+
+
+def acrobot_scale_roots(synthetic):
+    """Leg a's roots (the same formula as tests/golden/gen_golden.py acrobot_scale_roots): the engine's synthetic Acrobot roots (hanging,
+    at rest) mapped onto the upswing -- theta1 = 1.4 + 6 s0, theta2 = 8 s1, dtheta1 = 3 + 20 s2, dtheta2 = 20 s3; a mapped root that is
+    already above the line is replaced by a fixed one."""
+    from alphazero_gym_amd.envs import AcrobotEnv
+    s = np.asarray(synthetic)
+    roots = np.stack([1.4 + 6.0 * s[:, 0], 8.0 * s[:, 1], 3.0 + 20.0 * s[:, 2], 20.0 * s[:, 3]], 1)
+    for i, r in enumerate(roots):
+        if AcrobotEnv(state=r)._terminal():
+            roots[i] = [1.0, 0.0, 0.5, 0.0]
+    return roots
 
 
 def mcc_scale_roots(synthetic):
@@ -53,7 +68,8 @@ def mcc_scale_roots(synthetic):
 NAMES = {"c": "config C", "b": "config B", "e": "config E", "g": "the reference's default continuous setup (mixture head, 25 rollouts)",
          "d": "the reference's default discrete setup (epsilon-greedy 0.1, 8 rollouts)",
          "m": "MountainCar-v0 (three actions, 60 rollouts)",
-         "h": "MountainCarContinuous-v0 (continuous search with terminal nodes, 120 rollouts)"}
+         "h": "MountainCarContinuous-v0 (continuous search with terminal nodes, 120 rollouts)",
+         "a": "Acrobot-v1 (six observations, three actions, 50 rollouts)"}
 
 
 def _network(leg):
@@ -81,7 +97,7 @@ def attribute(tag, tree, ref_leaf, root):
     return d, (float(margin[0, d]) if d >= 0 else float("inf"))
 
 
-def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m", "h")):
+def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m", "h", "a")):
     z = np.load(os.path.join(P.GOLDEN, "t3_scale.npz"))
     total = matched = 0
     lines = []
@@ -91,7 +107,8 @@ def _scale(engine_cls, legs=("c", "b", "e", "g", "d", "m", "h")):
         B = len(roots)
         e = engine_cls(n_trees=B, n_sims=n_sims, **kw)
         # the fixture's roots are the engine's own synthetic roots 0..B-1 (leg h: mapped onto the slope below the flag)
-        np.testing.assert_array_equal(mcc_scale_roots(e.synthetic_roots()) if tag == "h" else e.synthetic_roots(), roots)
+        own = e.synthetic_roots()
+        np.testing.assert_array_equal(mcc_scale_roots(own) if tag == "h" else (acrobot_scale_roots(own) if tag == "a" else own), roots)
         e.set_weights(*_network(LEGS[tag]))
         e.search(roots)
         r = e.results()
