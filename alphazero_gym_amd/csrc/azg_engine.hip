@@ -240,7 +240,8 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
     e->opt.team_wide = env_digit("AZG_TEAM_WIDE", 1);
-    e->team_kc = 0; e->team_minb = 0;
+    e->team_kc = 0; e->team_minb = 0; e->team_tt = 32;
+    { const char* v = getenv("AZG_TEAM_TT"); e->opt.team_tt = v ? atoi(v) : 0; }
     { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
     e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0; e->team_fallbacks = 0; e->team_search_idx = 0;
     e->kernel_form = -1;
@@ -879,7 +880,7 @@ int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
         case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees, e->spec); break;
         case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
         case 2:
-            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb, e->spec);
+            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb, e->spec, e->team_tt);
             break;
         default: w = snprintf(buf, n, "(no search yet)");
     }

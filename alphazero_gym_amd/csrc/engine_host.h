@@ -26,8 +26,9 @@ struct EngineOptions {
     int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256);
                                // (made inside the first hidden layer's operand staging it cost +1 %: removed)
     int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
-    int team_wide;             // AZG_TEAM_WIDE=0: no three / four workgroups per CU forms of the team kernel (batches beyond two per CU
+    int team_wide;             // AZG_TEAM_WIDE=0: only the first form of the team kernel, 32-tree teams at two workgroups per CU (batches beyond that
                                // then take the per-layer launches)
+    int team_tt;               // AZG_TEAM_TT=32 / 64: only teams of that many trees (default 0: 32, and 64 for batches beyond two 32-tree workgroups per CU)
     long team_spin_limit;      // AZG_TEAM_SPIN_LIMIT=n: polls a team hand-off may wait before the launch gives up (tests: 0)
 };
 #define LS_MAX_PIPES 8
@@ -85,6 +86,7 @@ struct azg_engine {
     int team_pending;        // a team kernel has been launched since its abort word was last read
     int team_fallbacks;      // searches it gave up on (redone by the per-layer launches)
     uint32_t team_search_idx;
+    int team_tt;             // trees per team of the last team launch (32 or 64)
     int team_kc, team_minb;  // the team kernel form of the last launch (chunk length, workgroups per CU)
     int kernel_form;         // what the last search ran as: 0 search_kernel, 1 lock-step launches, 2 team kernel
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)

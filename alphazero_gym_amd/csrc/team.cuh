@@ -43,7 +43,7 @@
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
-#define LS_TILE_STAGE_F4(KC) (2 * (4 + 2) * (KC) * 64)   // float4 entries of the tile routine's two stages (TG = 2, UT = 4)
+#define LS_TILE_STAGE_F4(KC, TG) (2 * (4 + (TG)) * (KC) * 64)   // float4 entries of the tile routine's two stages (TG tree groups, UT = 4)
 
 struct TeamCtl {
     unsigned* cnt;         // [teams][TEAM_MAX_CNT][TEAM_CNT_STRIDE]
@@ -58,9 +58,9 @@ __host__ __device__ inline size_t team_tree_bytes(int R, bool cont, int tlds) {
     return (per + 15) / 16 * 16;
 }
 // (the stages double as the head partials' landing area between tiles: NCH * 64 float4, at most 16 * 64)
-__host__ __device__ inline size_t team_table_off(int kc) { size_t f4 = LS_TILE_STAGE_F4(kc); return (f4 < 1024 ? 1024 : f4) * 16; }
-__host__ __device__ inline size_t team_tree_off(int tab_n, int n_sims, int kc) {
-    return (team_table_off(kc) + (size_t)tab_n * 8 + (size_t)(n_sims + 2) * 4 + 15) / 16 * 16;
+__host__ __device__ inline size_t team_table_off(int kc, int tg = 2) { size_t f4 = LS_TILE_STAGE_F4(kc, tg); return (f4 < 1024 ? 1024 : f4) * 16; }
+__host__ __device__ inline size_t team_tree_off(int tab_n, int n_sims, int kc, int tg = 2) {
+    return (team_table_off(kc, tg) + (size_t)tab_n * 8 + (size_t)(n_sims + 2) * 4 + 15) / 16 * 16;
 }
 
 // all of this workgroup's hand-off stores are on their way: drain, meet, one lane arrives
@@ -106,18 +106,21 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
 // 1024 trees at HP = 1024; 3 and 4 (shorter chunks: smaller stages, fewer registers): larger batches -- while one workgroup of a
 // CU waits at a hand-off or walks its trees, the others keep the matrix pipe busy).
 // SPEC: compile-time knowledge about run-time parameters for the tree phases (tree_phases.cuh: Spec<>; 0 = the general code).
-template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2, int SPEC = 0>
+// TT: trees of a team, 32 or 64 (TGN = 2 or 4 tree groups: the tile is TT trees x 64 units; 64 halves the weight bytes staged per
+// MFMA and the barriers per MFMA, and needs twice the batch for the same number of workgroups).
+template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2, int SPEC = 0, int TT = 32>
 __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
     constexpr bool CONT = EnvFamily<ENV>::CONT;
-    constexpr int NU = HP / 64, NCH = HP / 64;
-    constexpr int TPW = 32 / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
-    static_assert(TPW >= 1 && TPW <= 4, "a team is 32 trees over HP/64 workgroups");
+    constexpr int NU = HP / 64, NCH = HP / 64, TGN = TT / 16;
+    constexpr int TPW = TT / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
+    static_assert(TT == 32 || TT == 64, "a team is two or four 16-tree groups");
+    static_assert(TPW >= 1 && TPW <= 4, "a team is TT trees over HP/64 workgroups");
     typedef typename TreeStore<TLDS>::Rec Rec;
     extern __shared__ f32x4 s_ab[];     // the tile routine's two stages (between tiles: the head partials of this workgroup's
                                         // trees), sqrt_tab [tab_n], pw_need [n_sims + 2], (LDS trees) the trees
     __shared__ float s_obs[32];         // [4 features][TPW] observations of this workgroup's new leaves, zero padded to a line
     __shared__ int s_ok;
-    double* s_sqrt = (double*)((char*)s_ab + team_table_off(KC));
+    double* s_sqrt = (double*)((char*)s_ab + team_table_off(KC, TGN));
     int* s_pw = (int*)(s_sqrt + P.tab_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     // team and slice of this workgroup: the NU workgroups of a team have equal blockIdx % 8 (one XCD under round-robin placement)
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
 #endif
     if (TQ % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8; tq = x * (TQ / 8) + j / NU; us = j % NU; }
     else { tq = blockIdx.x / NU; us = blockIdx.x % NU; }
-    const int g0 = 2 * tq;                                   // the team's tree groups g0, g0 + 1
+    const int g0 = TGN * tq;                                 // the team's tree groups g0 .. g0 + TGN - 1
     unsigned* cnt = T.cnt + (size_t)tq * TEAM_MAX_CNT * TEAM_CNT_STRIDE;
     const int n_layers = P.n_hidden - 1;                     // hidden->hidden layers 1 .. n_layers
 
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     const int tj = lane >> 4;                                // tree slot of the lane
     const bool has_tree = wave == 0 && tj < TPW;
     const int tt = us * TPW + (has_tree ? tj : 0);           // tree within the team: group g0 + tt / 16, column tt % 16
-    const int tree = tq * 32 + tt;
+    const int tree = tq * TT + tt;
     const bool live = has_tree && tree < P.B;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
     const size_t tb = (size_t)(live ? tree : 0) * P.R;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     float* action = P.action + tb;
     TreeStore<TLDS> ts;
     if constexpr (TLDS != TS_GLOBAL) {
-        char* base = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims, KC) + team_tree_bytes(P.R, CONT, TLDS) * (has_tree ? tj : 0);
+        char* base = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims, KC, TGN) + team_tree_bytes(P.R, CONT, TLDS) * (has_tree ? tj : 0);
         ts.hot = (Rec*)base;
         ts.pool = (typename TreeStore<TLDS>::PoolId*)(base + (size_t)P.R * 16);
         ts.prior = (float*)(base + (size_t)P.R * 16);
@@ -181,14 +184,15 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     const TileMem<true> act0(L.act[0], true);
     auto first_layer = [&](bool wt_now) {
         constexpr int TPT = 256 / TPW;                       // threads per tree
-        const int j = tid / TPT, u0 = (tid % TPT) * (HP / TPT);
-        static_assert(HP / TPT == 8, "8 units per thread");
+        constexpr int UPT = HP / TPT;                        // units per thread
+        const int j = tid / TPT, u0 = (tid % TPT) * UPT;
+        static_assert(UPT % 4 == 0, "whole float4s of units per thread");
         const int c = us * TPW + j;                          // the tree within the team: group g0 + c / 16, column c % 16
         const float x0 = s_obs[0 * TPW + j], x1 = s_obs[1 * TPW + j], x2 = s_obs[2 * TPW + j], x3 = s_obs[3 * TPW + j];
         TileMem<true> out = act0;
         out.wt = wt_now;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < UPT / 4; ++h) {
             const int u = u0 + 4 * h;
             f32x4 acc = P.b0u[u / 4];
             const f32x4 wa = P.W0u[u], wb = P.W0u[u + 1], wc = P.W0u[u + 2], wd = P.W0u[u + 3];
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
-            if (l == n_layers) ls_tile<HP, true, 2, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
-            else ls_tile<HP, false, 2, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+            if (l == n_layers) ls_tile<HP, true, TGN, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile<HP, false, TGN, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
             if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;

@@ -9,15 +9,15 @@
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
 // wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
 // otherwise it takes whatever the occupancy query allows (up to 6).
-template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0>
+template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0, int TT = 32>
 static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
-    constexpr int NU = HP / 64, TPW = 32 / NU;
+    constexpr int NU = HP / 64, TPW = TT / NU, TGN = TT / 16;
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
-    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + 1) / 2;
-    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
+    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + TGN - 1) / TGN;
+    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC, TGN) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
     if ((lds + 1024) * MINB > 160 * 1024) return hipErrorNotReady;
-    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB, SPEC>;
+    auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB, SPEC, TT>;
     // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel)
     static std::atomic<int> per_cu_caches[AZG_MAX_DEVICES];
     static std::atomic<size_t> lds_caches[AZG_MAX_DEVICES];
@@ -49,29 +49,35 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     e->kernel_form = 2;
     e->tree_lds = TLDS;
     e->dyn_lds = lds;
-    e->team_kc = KC; e->team_minb = MINB; e->spec = SPEC;
+    e->team_kc = KC; e->team_minb = MINB; e->spec = SPEC; e->team_tt = TT;
     return hipGetLastError();
 }
 
-// Two workgroups per CU with the long chunks while the batch fits that (1024 trees at HP = 1024: BASELINE config E per GPU); three,
-// then four per CU with short chunks for larger batches (HP = 1024, LDS trees: the shapes that were measured).
+// Forms by batch size (HP = 1024, LDS trees: the shapes that were measured; MI355X, 4x1024 network, 200 simulations):
+//   <= 2 workgroups of 32-tree teams per CU (1024 trees: BASELINE config E per GPU)   long chunks, two per CU            13.1 ms
+//   <= 3 per CU (1536 trees)                                                           short chunks, three per CU         18.8 ms
+//   <= 2 workgroups of 64-TREE teams per CU (2048 trees)   64 x 64 tiles: a third fewer staged bytes per MFMA             23.3 ms (0.70 of the
+//        fp32 MFMA peak; round 4's four 32-tree workgroups per CU, 62 spilled VGPRs: 24.3-25.0 ms -- removed)
+//   <= 3 of those per CU (3072 trees)                                                                                      32.9 ms (0.75; per-layer
+//        launches: 38.2 ms)
+// AZG_TEAM_WIDE=0: the first form only; AZG_TEAM_TT=32 / 64: only teams of that size (A/B runs).
 template <int ENV, int HP, bool GMM, int TLDS>
 static hipError_t team_launch(azg_engine* e) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
-    hipError_t rc;
-    // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
-    const bool common = WIDE && e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
-    if constexpr (WIDE) {
-        if (common) rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, e->opt.team_wide);
-        else rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, e->opt.team_wide);
-    } else {
-        rc = team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false);
+    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false);
+    else {
+        // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
+        const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
+        const bool wide = e->opt.team_wide != 0, t32 = e->opt.team_tt != 64, t64 = e->opt.team_tt != 32 && wide;
+        hipError_t rc = hipErrorNotReady;
+        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, wide) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, wide);
+        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);
+        // (64-tree teams: the long chunks' stages + four 200-simulation trees are 84 KB, two of that do not fit a CU; short chunks: 52 KB)
+        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1, 64>(e, true) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 0, 64>(e, true);
+        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 1, 64>(e, true) : team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 0, 64>(e, true);
+        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3, 0, 64>(e, false);
+        return rc;
     }
-    if constexpr (WIDE) {
-        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);
-        if (rc == hipErrorNotReady && e->opt.team_wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 4>(e, false);
-    }
-    return rc;
 }
 
 // trees in the workgroups' LDS when they fit (same rule as the persistent search kernel's), else in global memory

@@ -651,14 +651,18 @@ def main():
                              "fraction is small by construction, the HBM-side figure of SURVEY 8d is in roofline_hbm; selections are taken at "
                              "backup time and stored with the nodes, the descent follows them", dev, hbm=True, live=("B", "search_kernel")),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
-                             "ls_team_kernel<2, 1024, false, 1, 4, 2, 1>",
+                             "ls_team_kernel<2, 1024, false, 1, 4, 2, 1, 32>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
                              "layer for the team's 32 trees each), hand-offs through global memory; traffic = L2 misses of the cross-XCD "
                              "activation hand-offs (DESIGN.md section 3), the weights stay L2-resident", dev, live=("E", "ls_team_kernel")),
                 extra_config("E's network at 2048 trees per GPU", PENDULUM, 2048, 200, 3, [1024] * 4, 2, "elu",
-                             "ls_team_kernel<2, 1024, false, 1, 2, 4, 0>",
-                             mlp_flops(3, [1024] * 4, 3), "the team kernel's four-workgroups-per-CU form (short staging chunks): while one workgroup of a CU waits "
-                             "at a hand-off or walks its trees the other three keep the matrix pipe busy", dev),
+                             "ls_team_kernel<2, 1024, false, 1, 2, 2, 1, 64>",
+                             mlp_flops(3, [1024] * 4, 3), "the team kernel with teams of 64 trees (64 x 64 tiles: a third fewer staged bytes per MFMA than the "
+                             "32-tree teams' 32 x 64), two workgroups per CU, short staging chunks", dev),
+                extra_config("E's network at 3072 trees per GPU", PENDULUM, 3072, 200, 3, [1024] * 4, 2, "elu",
+                             "ls_team_kernel<2, 1024, false, 1, 2, 3, 0, 64>",
+                             mlp_flops(3, [1024] * 4, 3), "64-tree teams, three workgroups per CU: while one waits at a hand-off or walks its trees the "
+                             "other two keep the matrix pipe busy", dev),
             ]
         traffic, traffic_note = None, ("not measured in the N > 1 loop (the search kernel is the one of the N = 1 line: same launch, same "
                                        "traffic; rocprofv3 child passes are not started from inside a running multi-rank job)")
