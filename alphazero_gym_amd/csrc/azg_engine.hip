@@ -103,7 +103,7 @@ static int ls_prepare(azg_engine* e) {
 // team-kernel workgroup (16 workgroups per 32 trees, at least one team).
 static size_t stamp_rows(size_t B) {
     size_t r = ((B + 3) / 4) * 4;
-    const size_t r8 = ((B + 15) / 16) * 8, team = ((B + 31) / 32) * 16 / 2;
+    const size_t r8 = ((B + 15) / 16) * 8, team = ((B + 31) / 32) * 16 * 3 / 2;   // (team kernel: 8 + 16 counters per workgroup)
     if (r8 > r) r = r8;
     if (team > r) r = team;
     return r < 16 ? 16 : r;

@@ -79,11 +79,16 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
         if (T.spin_limit == 0u) {   // (tests: every wait counts as timed out)
             __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = 0;
-        } else while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 15u) == 0u) {
-                if (spins > T.spin_limit) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        } else {
+            // (Round 5 measured two polls in flight, half a round trip apart, so that a poll issued just before the counter moves is
+            // followed by one that sees it sooner: 13.20 against 13.15 ms per search at 1024 trees, 23.32 against 23.29 at 2048 -- a wait
+            // ends when the slowest of the team's workgroups arrives, not when the poll notices; not kept.)
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 15u) == 0u) {
+                    if (spins > T.spin_limit) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                }
             }
         }
         *s_ok = ok;
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     // diagnostic build: cycles of this workgroup (thread 0's clock) in  0 wait for observations | 1..3 tile of layer 1..3 |
     // 4 arrive + wait between layers | 5 wait for the last layer | 6 tree phases | 7 whole loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ... and the tree phases' own parts (tree_phases.cuh: slots 4..15 as in the search kernel's profile; here also 0 head partials into
+    // LDS | 1 phase A | 2 phase B | 3 first layer + arrive), thread 0's clock again: a second block of 16 per workgroup behind the first
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     TSTAMP(t_begin);
     for (int k = 0; k <= P.n_sims; ++k) {                    // evaluation k follows trace k - 1 (k = 0: the roots)
@@ -250,17 +258,20 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
             s_ab[w * 64 + q * 16 + j] = parts_mem.load4(((size_t)(g0 + c / 16) * NCH + w) * 64 + q * 16 + c % 16);
         }
         __syncthreads();
-#ifdef AZG_STAMPS
-        unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (the tree phases' own stamps: discarded here)
-#endif
+        TSTAMP(tp0);
         __builtin_amdgcn_s_setprio(3);   // the walking wave ahead of the other workgroups' MFMA waves on its SIMD (-0.7 % per search)
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt STAMP_ARG);
         st.need_eval = false;
+        TSTAMP(tp1);
         if (k < P.n_sims) {
             __threadfence_block();
             if (live) tree_phase_b<ENV, TLDS, GMM, TPW, int, true, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
         }
         __builtin_amdgcn_s_setprio(0);   // (after the tree phases on every path, the last step's included)
+        TSTAMP(tp2);
+#ifdef AZG_STAMPS
+        st_acc[0] += tp0 - te; st_acc[1] += tp1 - tp0; st_acc[2] += tp2 - tp1;
+#endif
         if (k < P.n_sims) {
             __syncthreads();
             first_layer(wt);
@@ -268,6 +279,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         }
         TSTAMP(tf);
         TADD(6, te, tf);
+#ifdef AZG_STAMPS
+        st_acc[3] += tf - tp2;
+#endif
     }
     // ---- the trees as the results kernels read them
     if (live) {
@@ -296,6 +310,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     tacc[0] = (unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
               ((unsigned long long)blockIdx.x << 40);
 #endif
-    if (tid == 0) for (int i = 0; i < 8; ++i) P.stamps[((size_t)tq * NU + us) * 8 + i] = tacc[i];
+    if (tid == 0) {
+        for (int i = 0; i < 8; ++i) P.stamps[((size_t)tq * NU + us) * 8 + i] = tacc[i];
+        for (int i = 0; i < 16; ++i) P.stamps[(size_t)gridDim.x * 8 + ((size_t)tq * NU + us) * 16 + i] = st_acc[i];
+    }
 #endif
 }
