@@ -654,7 +654,8 @@ int azg_search_resident(azg_engine* e) {
     e->team_search_idx = e->search_idx;
     const bool lockstep = use_lockstep(e);
     if (lockstep) { int prc = ls_prepare(e); if (prc) return prc; }
-    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    e->launch_timed = 0;
+    if (lockstep) HIPCHK(e, hipEventRecord(e->ev0, e->stream));   // (several launches; the one-launch search kernel stamps ev0 / ev1 itself)
     hipError_t rc;
     const bool cartpole = e->cfg.mode == AZG_MODE_DISCRETE;   // the discrete family's kernels (CartPole, MountainCar)
     const bool mcc = e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT;   // the continuous family whose episodes end (env.cuh: EnvFamily)
@@ -664,7 +665,7 @@ int azg_search_resident(azg_engine* e) {
     else if (mcc) rc = azg_dispatch_mcc(e);
     else rc = e->HP <= 128 ? azg_dispatch_pendulum_small(e) : azg_dispatch_pendulum_large(e);
     if (rc != hipSuccess) return fail(e, AZG_E_DEVICE, std::string("search kernel launch: ") + hipGetErrorString(rc));
-    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    if (!e->launch_timed) HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     e->search_idx += 1;
     e->searched = 1;
     e->results_valid = e->kernel_form == 0 ? 1 : 0;   // the one-launch search kernel writes return_results in its epilogue

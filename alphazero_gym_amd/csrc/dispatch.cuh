@@ -1,6 +1,7 @@
 // dispatch.cuh -- host-side choice and launch of the persistent search kernel variants (included by the dispatch_*.hip
 // translation units, each of which instantiates one family of them).
 #pragma once
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <cstdlib>
 
@@ -46,7 +47,10 @@ static hipError_t launch_g(azg_engine* e) {
     e->dyn_lds = L.total;
     e->waves = NW; e->groups = NG; e->tile_trees = NT; e->spec = SPEC;
     e->kernel_form = 0;
-    hipLaunchKernelGGL(kern, grid, block, L.total, e->stream, e->P);
+    // the launch carries its own start / stop events (azg_last_search_ms): stamps of the dispatch packet itself -- event records
+    // around it are two more packets in the queue, 7 us per search on a stream of back-to-back searches (measured, config C)
+    hipExtLaunchKernelGGL(kern, grid, block, (unsigned)L.total, e->stream, e->ev0, e->ev1, 0, e->P);
+    e->launch_timed = 1;
     return hipGetLastError();
 }
 
