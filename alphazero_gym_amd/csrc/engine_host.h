@@ -87,6 +87,7 @@ struct azg_engine {
     int team_fallbacks;      // searches it gave up on (redone by the per-layer launches)
     uint32_t team_search_idx;
     int team_tt;             // trees per team of the last team launch (32 or 64)
+    int team_parts;          // launches the last team search was cut into (batches beyond the widest form)
     int team_kc, team_minb;  // the team kernel form of the last launch (chunk length, workgroups per CU)
     int launch_timed;        // the last search's launch recorded ev0 / ev1 itself (hipExtLaunchKernelGGL)
     int kernel_form;         // what the last search ran as: 0 search_kernel, 1 lock-step launches, 2 team kernel

@@ -114,7 +114,7 @@ __device__ __forceinline__ bool team_wait(const unsigned* c, unsigned target, co
 // TT: trees of a team, 32 or 64 (TGN = 2 or 4 tree groups: the tile is TT trees x 64 units; 64 halves the weight bytes staged per
 // MFMA and the barriers per MFMA, and needs twice the batch for the same number of workgroups).
 template <int ENV, int HP, bool GMM, int TLDS, int KC = LS_KC, int MINB = 2, int SPEC = 0, int TT = 32>
-__global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ) {
+__global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep L, TeamCtl T, int TQ, int g_base) {
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int NU = HP / 64, NCH = HP / 64, TGN = TT / 16;
     constexpr int TPW = TT / NU;        // trees a workgroup owns: 16 lanes each, the first 16 * TPW lanes of wave 0
@@ -140,15 +140,16 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
 #endif
     if (TQ % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8; tq = x * (TQ / 8) + j / NU; us = j % NU; }
     else { tq = blockIdx.x / NU; us = blockIdx.x % NU; }
-    const int g0 = TGN * tq;                                 // the team's tree groups g0 .. g0 + TGN - 1
-    unsigned* cnt = T.cnt + (size_t)tq * TEAM_MAX_CNT * TEAM_CNT_STRIDE;
+    // (a batch too large for one launch runs as several, one after the other: this launch's TQ teams start at tree group g_base)
+    const int g0 = g_base + TGN * tq;                        // the team's tree groups g0 .. g0 + TGN - 1
+    unsigned* cnt = T.cnt + (size_t)(g0 / 2) * TEAM_MAX_CNT * TEAM_CNT_STRIDE;   // (one block of counters per 32 trees: a 64-tree team uses every other one)
     const int n_layers = P.n_hidden - 1;                     // hidden->hidden layers 1 .. n_layers
 
     // ---- this workgroup's trees
     const int tj = lane >> 4;                                // tree slot of the lane
     const bool has_tree = wave == 0 && tj < TPW;
     const int tt = us * TPW + (has_tree ? tj : 0);           // tree within the team: group g0 + tt / 16, column tt % 16
-    const int tree = tq * TT + tt;
+    const int tree = g0 * 16 + tt;
     const bool live = has_tree && tree < P.B;
     const unsigned gtree = (unsigned)(P.tree_base + tree);
     const size_t tb = (size_t)(live ? tree : 0) * P.R;

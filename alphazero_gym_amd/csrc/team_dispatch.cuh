@@ -10,11 +10,11 @@
 // wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
 // otherwise it takes whatever the occupancy query allows (up to 6).
 template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0, int TT = 32>
-static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
+static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_base, int G) {
     constexpr int NU = HP / 64, TPW = TT / NU, TGN = TT / 16;
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
-    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG, TQ = (G + TGN - 1) / TGN;
+    const int TQ = (G + TGN - 1) / TGN;   // (this launch: G tree groups from g_base)
     const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC, TGN) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
     if ((lds + 1024) * MINB > 160 * 1024) return hipErrorNotReady;
     auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB, SPEC, TT>;
@@ -38,13 +38,13 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
     int usable = per_cu < 6 ? per_cu : 6;
     if (wider_form_exists && usable > MINB) usable = MINB;   // (the next form takes the larger batches)
     if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
-    hipError_t rc = hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream);
+    hipError_t rc = g_base == 0 ? hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream) : hipSuccess;
     if (rc != hipSuccess) return rc;
     TeamCtl T;
     T.cnt = e->d_team_cnt;
     T.abort = e->d_team_cnt + (e->team_cnt_bytes / 4 - 1);   // the last word
     T.spin_limit = (unsigned)e->opt.team_spin_limit;
-    hipLaunchKernelGGL(kern, dim3(TQ * NU), dim3(256), lds, e->stream, e->P, e->ls, T, TQ);
+    hipLaunchKernelGGL(kern, dim3(TQ * NU), dim3(256), lds, e->stream, e->P, e->ls, T, TQ, g_base);
     e->team_pending = 1;
     e->kernel_form = 2;
     e->tree_lds = TLDS;
@@ -62,22 +62,41 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists) {
 //        launches: 38.2 ms)
 // AZG_TEAM_WIDE=0: the first form only; AZG_TEAM_TT=32 / 64: only teams of that size (A/B runs).
 template <int ENV, int HP, bool GMM, int TLDS>
-static hipError_t team_launch(azg_engine* e) {
+static hipError_t team_launch_part(azg_engine* e, int g_base, int G) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
-    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false);
+    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false, g_base, G);
     else {
         // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
         const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
         const bool wide = e->opt.team_wide != 0, t32 = e->opt.team_tt != 64, t64 = e->opt.team_tt != 32 && wide;
         hipError_t rc = hipErrorNotReady;
-        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, wide) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, wide);
-        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true);
+        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, wide, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, wide, g_base, G);
+        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true, g_base, G);
         // (64-tree teams: the long chunks' stages + four 200-simulation trees are 84 KB, two of that do not fit a CU; short chunks: 52 KB)
-        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1, 64>(e, true) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 0, 64>(e, true);
-        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 1, 64>(e, true) : team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 0, 64>(e, true);
-        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3, 0, 64>(e, false);
+        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 0, 64>(e, true, g_base, G);
+        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 0, 64>(e, true, g_base, G);
+        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3, 0, 64>(e, false, g_base, G);
         return rc;
     }
+}
+
+// Batches beyond the widest form (3072 trees at HP = 1024) run as TWO launches of equal parts, one after the other on the engine's
+// stream (trees are independent; a launch's workgroups all have to be resident at once): 4096 trees 46.5 ms against 48.7 ms for the
+// per-layer launches.  Those get better with the batch (8192 trees: 92.7 ms = 0.71 of the fp32 MFMA peak; three team launches: 99.2 ms):
+// batches of more than two parts are theirs.
+template <int ENV, int HP, bool GMM, int TLDS>
+static hipError_t team_launch(azg_engine* e) {
+    constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
+    const int G = (e->cfg.n_trees + TREES_PER_WG - 1) / TREES_PER_WG;
+    const int G_MAX = 3 * e->n_cus / (HP / 64) * 4;                      // 64-tree teams, three workgroups on every CU
+    e->team_parts = 1;
+    if (!WIDE || G <= G_MAX || !e->opt.team_wide || e->opt.team_tt == 32) return team_launch_part<ENV, HP, GMM, TLDS>(e, 0, G);
+    const int parts = (G + G_MAX - 1) / G_MAX, per = ((G + parts - 1) / parts + 3) / 4 * 4;   // (whole 64-tree teams)
+    if (parts > 2) return hipErrorNotReady;
+    hipError_t rc = hipSuccess;
+    for (int g = 0; g < G && rc == hipSuccess; g += per) rc = team_launch_part<ENV, HP, GMM, TLDS>(e, g, G - g < per ? G - g : per);
+    e->team_parts = parts;
+    return rc;
 }
 
 // trees in the workgroups' LDS when they fit (same rule as the persistent search kernel's), else in global memory

@@ -750,11 +750,12 @@ def test_random_tie_break_is_the_same_on_the_device_and_the_oracle(native, kw):
         assert not np.array_equal(a[0]["counts"], first[0]["counts"])   # (Pendulum's sampled actions make ties rare: no claim there)
 
 
-@pytest.mark.parametrize("B,eps", [(1536, 0.0), (2048, 0.0), (2000, 0.1), (3072, 0.0)])
+@pytest.mark.parametrize("B,eps", [(1536, 0.0), (2048, 0.0), (2000, 0.1), (3072, 0.0), (4136, 0.0)])
 def test_team_kernel_beyond_two_workgroups_per_cu(native, B, eps, monkeypatch):
     """Batches beyond two 32-tree team workgroups per CU (config E's network with more than 1024 trees per GPU) run the team kernel's
     other forms: three short-chunk workgroups per CU (1536 trees), then teams of 64 trees -- 64 x 64 tiles, a workgroup walks four
-    trees -- two (2048; specialised and, with eps-greedy, general tree phases) and three (3072) per CU.  Same arithmetic as the
+    trees -- two (2048; specialised and, with eps-greedy, general tree phases) and three (3072) per CU; beyond that the batch runs as
+    several launches of equal parts (4136 trees: two).  Same arithmetic as the
     per-layer launches: identical trees, record for record (the launches are checked against the oracle at config E's size above); a
     ragged slice of the batch also against the oracle."""
     NS = 24

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import numpy as np
 from alphazero_gym_amd import _capi, _native
 from alphazero_gym_amd.synthetic import make_weights
-for B in (1024, 1536, 2048, 3072):
+for B in (1024, 1536, 2048, 3072, 4096):
     e = _native.HipEngine(env_id=2, mode=1, n_trees=B, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), make_weights(34, 3, [1024] * 4, 2))
     e.upload_roots(e.synthetic_roots())
