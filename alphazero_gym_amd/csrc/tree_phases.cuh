@@ -1,6 +1,9 @@
 // tree_phases.cuh -- the two tree phases of one simulation step for one tree (16 lanes), shared by the persistent search
 // kernel (search_kernel.cuh) and the lock-step kernels for wide networks (lockstep.cuh).
 #pragma once
+#ifndef EARLY_COLD
+#define EARLY_COLD 1   // tree_phase_b, continuous mode: see there (measured: 2x128 networks -0.7 %, config C within noise)
+#endif
 #include "records.h"
 #include "env.cuh"
 #include "mlp.cuh"
@@ -454,6 +457,11 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         STAMP(tl1);
         STAMP_ADD(7, tl0, tl1);    // the level's selection
         STAMP(tl2);
+        // continuous mode: the chosen child's cold record (its cached policy and env state: needed at once if the trace widens there)
+        // is requested before the hot record's LDS round trip, not after it (an edge without a child node: a record of the tree all
+        // the same, its contents unused)
+        Cold cn;
+        if constexpr (CONT && EARLY_COLD) cn = cold[chosen];
         Rec hc = ts.hot[chosen];
         if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it
         STAMP(tl3);
@@ -464,7 +472,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             st.my_depth = st.path_D; st.pid = chosen;
             // continuous mode (2-3 levels, a slow scored descent): fetched here, in the shadow of the level's LDS waits;
             // discrete mode (8-9 levels of pointer chasing): all levels at once after the loop (measured both ways)
-            if (CONT && FETCH) { st.pr = cold[chosen].r; st.pW = edge_W[chosen]; }
+            if (CONT && FETCH) { st.pr = EARLY_COLD ? cn.r : cold[chosen].r; st.pW = edge_W[chosen]; }
             if (!CONT && FETCH) { st.pr = r_step; st.pW = edge_W[chosen]; }   // (consumed by the backup; requested as the record enters the path)
         }
         if constexpr (EnvFamily<ENV>::TERM) {   // (Pendulum never terminates: no exit, and no exit mask to maintain, in its kernels)
@@ -473,7 +481,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         }
         // the node's env state for the step that follows if the trace leaves the tree here: requested at every level, the wave
         // waits only for the last one (Pendulum: the whole cold record, its widening needs the cached policy too)
-        if (CONT) cp = cold[p];
+        if (CONT) { if constexpr (EARLY_COLD) cp = cn; else cp = cold[p]; }
         else if (from_cold) { cp.s[0] = cold[p].s[0]; cp.s[1] = cold[p].s[1]; cp.s[2] = cold[p].s[2]; cp.s[3] = cold[p].s[3]; }
         // (LDS-resident env states: read once, below, for the node the trace leaves the tree from)
         STAMP(tl4);
