@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
 #if TEAM_SPREAD
     // A team's slices are SPREAD over the XCDs (blockIdx % 8 = XCD under round-robin dispatch: NU / 8 slices on each), so that
     // every XCD's 4 MB L2 keeps just its own slices' weights resident (1.5 MB at 4x1024) instead of streaming all 12.6 MB of them
-    // from the Infinity Cache every step; the hand-offs then cross XCDs (sc1 stores and loads).  Measured 13.3 ms per search
-    // against 14.5 ms with each team on one XCD (plain hand-off stores into its L2): the weights matter more.
+    // from the Infinity Cache every step; the hand-offs then cross XCDs (sc1 stores and loads).  Measured 13.1 ms per search
+    // against 14.8 ms with each team on one XCD (plain hand-off stores into its L2; round 5, 64-tree teams: 23.3 / 24.2 ms at 2048 trees,
+    // 32.8 / 33.4 at 3072): the weights matter more.
     if (NU % 8 == 0) { const int x = blockIdx.x % 8, j = blockIdx.x / 8, sp = NU / 8; tq = j / sp; us = x * sp + j % sp; }
     else
 #endif
