@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #define LS_KC 4
 #endif
 #ifndef LS_PIPE
-#define LS_PIPE 3        // operand staging schedule of the tiled layer kernel (see there)
+#define LS_PIPE 4        // operand staging schedule of the tiled layer kernel (see there)
 #endif
 #ifndef LS_XCD_2D
 #define LS_XCD_2D 1      // XCD-rectangle block mapping (0: unit slices per XCD)
@@ -261,6 +261,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     constexpr int WPG = 4 / TG;            // waves per tree group
     constexpr int WT = UT / WPG;           // unit tiles per wave
     constexpr int S4 = HP / 16, NU = HP / (16 * UT), KC = KC_, NCHUNK = S4 / KC;
+    constexpr int PIPE = LS_PIPE == 4 && KC < 4 ? 3 : LS_PIPE;   // (schedule 4 pays with long chunks only: see below)
     static_assert(S4 % KC == 0, "k-blocks per layer must be a multiple of the chunk");
     constexpr int ASZ = UT * KC * 64, BSZ = TG * KC * 64;   // float4 entries of a stage's A [UT tiles][KC][64] and B [TG groups][KC][64]
     constexpr int STAGE = ASZ + BSZ;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     for (int i = 0; i < WT; ++i) acc[i] = P.bl[layer - 1][(t0 + wt0 + i) * 64 + lane];
     load_chunk(0);
     store_chunk(0);
-    if (LS_PIPE >= 2 && NCHUNK > 1) load_chunk(1);
+    if (PIPE >= 2 && NCHUNK > 1) load_chunk(1);
     __syncthreads();
     // the bias has to have arrived before the loop: a wait for it inside the loop would, from the second pass on, wait for the
     // next chunk's loads instead (waitcnt placement is static)
@@ -318,10 +319,10 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     // front of the stores then name exactly the loads they need, not "everything in flight")
     auto chunk = [&](int c, auto has1_t, auto has2_t) {
         constexpr bool has1 = decltype(has1_t)::value, has2 = decltype(has2_t)::value;
-        if (LS_PIPE == 2) {
+        if (PIPE == 2) {
             if (has1) store_chunk((c + 1) & 1);
             if (has2) load_chunk(c + 2);
-        } else if (LS_PIPE == 1 && has1) load_chunk(c + 1);       // in flight under this chunk's MFMAs
+        } else if (PIPE == 1 && has1) load_chunk(c + 1);       // in flight under this chunk's MFMAs
         const f32x4* sB = s_ab + (c & 1) * STAGE + ASZ + wg * KC * 64;
         const f32x4* sA = s_ab + (c & 1) * STAGE + wt0 * KC * 64;
         // operands of k-block s+1 are read from LDS while the MFMAs of k-block s run
@@ -341,7 +342,7 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
             for (int cmp = 0; cmp < 4; ++cmp) {
 #pragma unroll
                 for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][cmp], b[cmp], acc[i], 0, 0, 0);
-                if (LS_PIPE == 3) {
+                if (PIPE == 3) {
                     const int q = 4 * s + cmp;
                     if (q >= SLOT0 && (q - SLOT0) % SLOTD == 0 && (q - SLOT0) / SLOTD < NL) {
                         const int j = (q - SLOT0) / SLOTD;
@@ -358,14 +359,80 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
                 for (int i = 0; i < WT; ++i) a[i] = an[i];
             }
         }
-        if (LS_PIPE == 1 && has1) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
+        if (PIPE == 1 && has1) store_chunk((c + 1) & 1);   // the other stage: its readers passed the previous barrier
         if (!(DBG & 2)) __syncthreads();
     };
+    //   4  like 3, and the chunk's barrier stands in FRONT of its last k-block's MFMAs instead of behind them: that block's operands
+    //      are in registers by then and every staging store of the chunk is issued (the pieces are dealt out over the first KC - 1
+    //      k-blocks), so the first operands of the NEXT chunk are requested right behind the barrier and arrive under those MFMAs --
+    //      the wave no longer starts every chunk with an LDS round trip that nothing covers (a workgroup that has its CU to itself:
+    //      one wave per SIMD).  The barrier is a bare s_barrier behind lgkmcnt(0): the global loads in flight are not its business.
+    //      Measured (MI355X, 4x1024 network, ms per search, schedule 3 -> 4): 512 trees (one workgroup per CU) 8.97 -> 8.71, 1024 trees
+    //      13.08 -> 12.98, per-layer launches at 8192 trees 92.1 -> 90.0; with KC = 2 the pieces crowd into one k-block and it loses
+    //      (1536 trees 18.64 -> 19.09, 3072 trees 32.63 -> 32.99): those forms keep schedule 3.
+    constexpr int NS4 = 4 * (KC - 1), SLOTD4 = NS4 / NL > 0 ? NS4 / NL : 1, SLOT04 = NS4 > NL * SLOTD4 ? 1 : 0;
+    static_assert(PIPE != 4 || NS4 >= NL, "schedule 4 deals the staging pieces out over the first KC - 1 k-blocks");
+    f32x4 ca[WT], cb;   // schedule 4: operands of the k-block that runs next, carried from chunk to chunk
+    auto chunk4 = [&](int c, auto has1_t, auto has2_t) {
+        constexpr bool has1 = decltype(has1_t)::value, has2 = decltype(has2_t)::value;
+        const f32x4* sB = s_ab + (c & 1) * STAGE + ASZ + wg * KC * 64;
+        const f32x4* sA = s_ab + (c & 1) * STAGE + wt0 * KC * 64;
+        f32x4 an[WT], bn;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            if (s + 1 < KC) {
+                if (!(DBG & 4)) {
+                    bn = sB[(s + 1) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) an[i] = sA[(i * KC + s + 1) * 64 + lane];
+                }
+            } else {
+                if (!(DBG & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (has1 && !(DBG & 4)) {
+                    const f32x4* sBn = s_ab + ((c + 1) & 1) * STAGE + ASZ + wg * KC * 64;
+                    const f32x4* sAn = s_ab + ((c + 1) & 1) * STAGE + wt0 * KC * 64;
+                    bn = sBn[lane];
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) an[i] = sAn[(i * KC) * 64 + lane];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cmp = 0; cmp < 4; ++cmp) {
+#pragma unroll
+                for (int i = 0; i < WT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i][cmp], cb[cmp], acc[i], 0, 0, 0);
+                const int q = 4 * s + cmp;
+                if (s + 1 < KC && q >= SLOT04 && (q - SLOT04) % SLOTD4 == 0 && (q - SLOT04) / SLOTD4 < NL) {
+                    const int j = (q - SLOT04) / SLOTD4;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has1 && !(DBG & 2)) store_one((c + 1) & 1, j);
+                    if (has2 && !(DBG & 1)) load_one(c + 2, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if ((s + 1 < KC || has1) && !(DBG & 4)) {
+                cb = bn;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) ca[i] = an[i];
+            }
+        }
+    };
     static_assert(NCHUNK >= 2, "the staging pipeline is written for at least two chunks");
+    (void)chunk; (void)chunk4;
+    if constexpr (PIPE == 4) {
+        cb = s_ab[ASZ + wg * KC * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < WT; ++i) ca[i] = s_ab[(wt0 + i) * KC * 64 + lane];
 #pragma unroll 1
-    for (int c = 0; c < NCHUNK - 2; ++c) chunk(c, std::true_type{}, std::true_type{});
-    chunk(NCHUNK - 2, std::true_type{}, std::false_type{});
-    chunk(NCHUNK - 1, std::false_type{}, std::false_type{});
+        for (int c = 0; c < NCHUNK - 2; ++c) chunk4(c, std::true_type{}, std::true_type{});
+        chunk4(NCHUNK - 2, std::true_type{}, std::false_type{});
+        chunk4(NCHUNK - 1, std::false_type{}, std::false_type{});
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < NCHUNK - 2; ++c) chunk(c, std::true_type{}, std::true_type{});
+        chunk(NCHUNK - 2, std::true_type{}, std::false_type{});
+        chunk(NCHUNK - 1, std::false_type{}, std::false_type{});
+    }
     if (DBG & 8) {
 #pragma unroll
         for (int j = 0; j < NLA; ++j) asm volatile("" ::"v"(ra[j]));

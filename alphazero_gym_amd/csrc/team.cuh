@@ -43,6 +43,9 @@
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
+#ifndef TEAM_TILE_DBG
+#define TEAM_TILE_DBG 0          // timing experiments only (lockstep.cuh: ls_tile's DBG): wrong results
+#endif
 #define LS_TILE_STAGE_F4(KC, TG) (2 * (4 + (TG)) * (KC) * 64)   // float4 entries of the tile routine's two stages (TG tree groups, UT = 4)
 
 struct TeamCtl {
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
-            if (l == n_layers) ls_tile<HP, true, TGN, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
-            else ls_tile<HP, false, TGN, 4, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+            if (l == n_layers) ls_tile<HP, true, TGN, 4, true, KC, TEAM_TILE_DBG>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile<HP, false, TGN, 4, true, KC, TEAM_TILE_DBG>(P, L, l, in_buf, us, g0, s_ab, wt);
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
             if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;
