@@ -472,6 +472,130 @@ __device__ __forceinline__ void ls_tile(const KParams& P, const LockStep& L, int
     }
 }
 
+// The same tile (TG tree groups x 4 unit tiles, one 256-thread workgroup) with the WEIGHTS NOT STAGED: wave w owns unit tile w for all
+// TG tree groups, so a weight block is the A operand of exactly one wave -- it goes from global memory (already in the MFMA's lane
+// layout) straight into that wave's registers, two chunks ahead, and only the activations, which all four waves share, pass through
+// LDS.  Against ls_tile: the same global loads per thread, a third (TG = 2) or half (TG = 4) of the staging stores, one LDS operand
+// read fewer per k-block, stages a third / half the size (LDS left for longer chunks: fewer barriers), and the weights' round trip has
+// two chunks to complete instead of one.  Same arithmetic: every accumulator is the same k-ordered chain from the bias.
+// Schedule: ls_tile's number 4 (barrier in front of the chunk's last k-block, the next chunk's first operands behind it).
+// s_b: two stages of TG * KC * 64 float4.
+template <int HP, bool LAST, int TG, bool SC1, int KC>
+__device__ __forceinline__ void ls_tile_wd(const KParams& P, const LockStep& L, int layer, int in_buf, int us, int g0, f32x4* s_b, bool wt = true) {
+    constexpr int S4 = HP / 16, NU = HP / 64, NCHUNK = S4 / KC;
+    constexpr int BSZ = TG * KC * 64;                 // float4 entries of a stage: [TG groups][KC][64]
+    constexpr int NLB = BSZ / 256;                    // float4 of the activations per thread per chunk
+    static_assert(S4 % KC == 0 && BSZ % 256 == 0 && NCHUNK >= 4 && NCHUNK % 2 == 0, "chunking");
+    static_assert(KC >= 2 && 4 * (KC - 1) >= NLB, "the staging pieces are dealt out over the first KC - 1 k-blocks");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = us * 4 + wave;                   // this wave's unit tile
+    const f32x4* W = P.Wl[layer - 1] + (size_t)tile * S4 * 64 + lane;   // k-block kb of it: W[kb * 64]
+    const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1], wt), parts(L.parts, wt);
+    f32x4 aw[2][KC];                                  // the weights of two chunks (set = chunk index & 1)
+    f32x4 rb[NLB];
+    auto load_b = [&](int c, int j) {
+        const int e = j * 256 + tid, i = e / (KC * 64), r = e % (KC * 64);
+        rb[j] = in.load4(((size_t)(g0 + i) * S4 + c * KC) * 64 + r);
+    };
+    auto store_b = [&](int st, int j) { s_b[st * BSZ + j * 256 + tid] = rb[j]; };
+    f32x4 acc[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) acc[g] = P.bl[layer - 1][tile * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < KC; ++s) aw[0][s] = W[s * 64];
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) load_b(0, j);
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) store_b(0, j);
+#pragma unroll
+    for (int s = 0; s < KC; ++s) aw[1][s] = W[(KC + s) * 64];
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) load_b(1, j);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < TG; ++g) asm volatile("" : "+v"(acc[g]));   // (the bias has arrived: see ls_tile)
+    f32x4 b[TG], bn[TG];                              // operands of the k-block that runs next, carried from chunk to chunk
+#pragma unroll
+    for (int g = 0; g < TG; ++g) b[g] = s_b[(g * KC) * 64 + lane];
+    constexpr int NS = 4 * (KC - 1), SLOTD = NS / NLB > 0 ? NS / NLB : 1, SLOT0 = NS > NLB * SLOTD ? 1 : 0;
+    auto chunk = [&](int c, auto set_t, auto has1_t, auto has2_t) {
+        constexpr int SET = decltype(set_t)::value;
+        constexpr bool has1 = decltype(has1_t)::value, has2 = decltype(has2_t)::value;
+        const f32x4* sB = s_b + SET * BSZ;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            if (s + 1 < KC) {
+#pragma unroll
+                for (int g = 0; g < TG; ++g) bn[g] = sB[(g * KC + s + 1) * 64 + lane];
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (has1) {
+                    const f32x4* sBn = s_b + (SET ^ 1) * BSZ;
+#pragma unroll
+                    for (int g = 0; g < TG; ++g) bn[g] = sBn[(g * KC) * 64 + lane];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 a = aw[SET][s];
+#pragma unroll
+            for (int cmp = 0; cmp < 4; ++cmp) {
+#pragma unroll
+                for (int g = 0; g < TG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cmp], b[g][cmp], acc[g], 0, 0, 0);
+                const int q = 4 * s + cmp;
+                if (s + 1 < KC && q >= SLOT0 && (q - SLOT0) % SLOTD == 0 && (q - SLOT0) / SLOTD < NLB) {
+                    const int j = (q - SLOT0) / SLOTD;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has1) store_b(SET ^ 1, j);
+                    if (has2) load_b(c + 2, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (has2) {   // this k-block's weights of the chunk after next, into the registers that just fed the matrix pipe
+                __builtin_amdgcn_sched_barrier(0);
+                aw[SET][s] = W[((c + 2) * KC + s) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s + 1 < KC || has1) {
+#pragma unroll
+                for (int g = 0; g < TG; ++g) b[g] = bn[g];
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK - 2; c += 2) {
+        chunk(c, S0{}, std::true_type{}, std::true_type{});
+        chunk(c + 1, S1{}, std::true_type{}, std::true_type{});
+    }
+    chunk(NCHUNK - 2, S0{}, std::true_type{}, std::false_type{});
+    chunk(NCHUNK - 1, S1{}, std::false_type{}, std::false_type{});
+    f32x4 h[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) h[g] = act4<true>(P.act, acc[g]);
+    if constexpr (!LAST) {
+#pragma unroll
+        for (int g = 0; g < TG; ++g) out.store4(((size_t)(g0 + g) * S4 + tile) * 64 + lane, h[g]);
+    } else {
+        // the slice's 64 units are one head chunk (chunk index = us): a chain from 0 over its 4 tiles, in tile order -- here from
+        // wave to wave through LDS (every read of the stages is behind the loop's last barrier)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int g = 0; g < TG; ++g) {
+                    f32x4 hs = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (w > 0) hs = s_b[g * 64 + lane];
+                    hs = mfma4(P.Whead[tile * 64 + lane], h[g], hs);
+                    if (w < 3) s_b[g * 64 + lane] = hs;
+                    else parts.store4(((size_t)(g0 + g) * NU + us) * 64 + lane, hs);
+                }
+            }
+            if (w < 3) __syncthreads();
+        }
+    }
+}
+
 // A hidden->hidden layer as a launch of its own: one tile per workgroup.
 template <int HP, bool LAST, int TG, int UT>
 __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockStep L, int layer, int in_buf, int TQ, int g_base) {

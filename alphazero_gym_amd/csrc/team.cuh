@@ -46,7 +46,14 @@
 #ifndef TEAM_TILE_DBG
 #define TEAM_TILE_DBG 0          // timing experiments only (lockstep.cuh: ls_tile's DBG): wrong results
 #endif
+#ifndef TEAM_WD
+#define TEAM_WD 1                // 1: ls_tile_wd (weights straight into registers, only the activations staged); 0: ls_tile
+#endif
+#if TEAM_WD
+#define LS_TILE_STAGE_F4(KC, TG) (2 * (TG) * (KC) * 64)          // float4 entries of the tile routine's two stages (activations only)
+#else
 #define LS_TILE_STAGE_F4(KC, TG) (2 * (4 + (TG)) * (KC) * 64)   // float4 entries of the tile routine's two stages (TG tree groups, UT = 4)
+#endif
 
 struct TeamCtl {
     unsigned* cnt;         // [teams][TEAM_MAX_CNT][TEAM_CNT_STRIDE]
@@ -245,8 +252,13 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         for (int l = 1; l <= n_layers; ++l) {
             const int in_buf = (l - 1) & 1;
             TSTAMP(ta);
+#if TEAM_WD
+            if (l == n_layers) ls_tile_wd<HP, true, TGN, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+            else ls_tile_wd<HP, false, TGN, true, KC>(P, L, l, in_buf, us, g0, s_ab, wt);
+#else
             if (l == n_layers) ls_tile<HP, true, TGN, 4, true, KC, TEAM_TILE_DBG>(P, L, l, in_buf, us, g0, s_ab, wt);
             else ls_tile<HP, false, TGN, 4, true, KC, TEAM_TILE_DBG>(P, L, l, in_buf, us, g0, s_ab, wt);
+#endif
             TSTAMP(tb_);
             team_arrive(cnt + l * TEAM_CNT_STRIDE);
             if (!team_wait(cnt + l * TEAM_CNT_STRIDE, (unsigned)(NU * (k + 1)), T, &s_ok)) return;

@@ -6,6 +6,17 @@
 #include "engine_host.h"
 #include "team.cuh"
 
+// chunk lengths of the forms (k-blocks per staged chunk)
+#ifndef TEAM_KC32
+#define TEAM_KC32 2         // 32-tree teams, two workgroups per CU (weights-direct tile, MI355X, ms per search at 1024 trees: 2: 12.78, 4: 13.2, 8: 13.24)
+#endif
+#ifndef TEAM_KC32W
+#define TEAM_KC32W 2        // 32-tree teams, three per CU (1536 trees: 2: 17.96, 4: 18.48)
+#endif
+#ifndef TEAM_KC64
+#define TEAM_KC64 2         // 64-tree teams, two / three per CU (2048 trees: 2: 22.45, 4: 23.04; 3072: 32.13 / 33.73)
+#endif
+
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
 // wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
 // otherwise it takes whatever the occupancy query allows (up to 6).
@@ -64,18 +75,17 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_
 template <int ENV, int HP, bool GMM, int TLDS>
 static hipError_t team_launch_part(azg_engine* e, int g_base, int G) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
-    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, false, g_base, G);
+    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, false, g_base, G);
     else {
         // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
         const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
         const bool wide = e->opt.team_wide != 0, t32 = e->opt.team_tt != 64, t64 = e->opt.team_tt != 32 && wide;
         hipError_t rc = hipErrorNotReady;
-        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1>(e, wide, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2>(e, wide, g_base, G);
-        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3>(e, true, g_base, G);
+        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2, 1>(e, wide, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, wide, g_base, G);
+        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32W, 3>(e, true, g_base, G);
         // (64-tree teams: the long chunks' stages + four 200-simulation trees are 84 KB, two of that do not fit a CU; short chunks: 52 KB)
-        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, LS_KC, 2, 0, 64>(e, true, g_base, G);
-        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, 2, 2, 0, 64>(e, true, g_base, G);
-        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, 2, 3, 0, 64>(e, false, g_base, G);
+        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 0, 64>(e, true, g_base, G);
+        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 3, 0, 64>(e, false, g_base, G);
         return rc;
     }
 }

@@ -651,7 +651,7 @@ def main():
                              "fraction is small by construction, the HBM-side figure of SURVEY 8d is in roofline_hbm; selections are taken at "
                              "backup time and stored with the nodes, the descent follows them", dev, hbm=True, live=("B", "search_kernel")),
                 extra_config("E (per GPU): Pendulum-v1, 1024 trees, n_sims=200, 4x1024 ELU", PENDULUM, 1024, 200, 3, [1024] * 4, 2, "elu",
-                             "ls_team_kernel<2, 1024, false, 1, 4, 2, 1, 32>",
+                             "ls_team_kernel<2, 1024, false, 1, 2, 2, 1, 32>",
                              mlp_flops(3, [1024] * 4, 3), "persistent team kernel: one launch per search, 32 teams of 16 workgroups (one 64-unit slice of every "
                              "layer for the team's 32 trees each), hand-offs through global memory; traffic = L2 misses of the cross-XCD "
                              "activation hand-offs (DESIGN.md section 3), the weights stay L2-resident", dev, live=("E", "ls_team_kernel")),
