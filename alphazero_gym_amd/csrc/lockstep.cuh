@@ -199,6 +199,13 @@ __global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, i
 #ifndef LS_PIPE
 #define LS_PIPE 4        // operand staging schedule of the tiled layer kernel (see there)
 #endif
+#ifndef LS_LAYER_WD
+#define LS_LAYER_WD 0    // the per-layer launches' tile: 1 = ls_tile_wd (weights straight into registers), 0 = ls_tile (measured: 15.93 against
+                         // 15.75 ms per search at 1024 trees, 91.5 against 90.9 at 8192 -- a kernel per layer has no hand-off waits to shorten)
+#endif
+#ifndef LS_LAYER_KC
+#define LS_LAYER_KC 2    // its chunk length (k-blocks)
+#endif
 #ifndef LS_XCD_2D
 #define LS_XCD_2D 1      // XCD-rectangle block mapping (0: unit slices per XCD)
 #endif
@@ -501,6 +508,8 @@ __device__ __forceinline__ void ls_tile_wd(const KParams& P, const LockStep& L, 
     f32x4 acc[TG];
 #pragma unroll
     for (int g = 0; g < TG; ++g) acc[g] = P.bl[layer - 1][tile * 64 + lane];
+    f32x4 whead = {0.0f, 0.0f, 0.0f, 0.0f};          // (last layer: this tile's head weights, requested here -- the head chain runs from
+    if constexpr (LAST) whead = P.Whead[tile * 64 + lane];   // wave to wave, a round trip to L2 in each link would be four in a row)
 #pragma unroll
     for (int s = 0; s < KC; ++s) aw[0][s] = W[s * 64];
 #pragma unroll
@@ -586,7 +595,7 @@ __device__ __forceinline__ void ls_tile_wd(const KParams& P, const LockStep& L, 
                 for (int g = 0; g < TG; ++g) {
                     f32x4 hs = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (w > 0) hs = s_b[g * 64 + lane];
-                    hs = mfma4(P.Whead[tile * 64 + lane], h[g], hs);
+                    hs = mfma4(whead, h[g], hs);
                     if (w < 3) s_b[g * 64 + lane] = hs;
                     else parts.store4(((size_t)(g0 + g) * NU + us) * 64 + lane, hs);
                 }
@@ -617,5 +626,6 @@ __global__ __launch_bounds__(256) void ls_hidden_tiled_kernel(KParams P, LockSte
         if (nb % 8 == 0) m = (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8;
         us = m / TQ; tq = m % TQ;
     }
-    ls_tile<HP, LAST, TG, UT, false>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
+    if constexpr (LS_LAYER_WD && UT == 4) ls_tile_wd<HP, LAST, TG, false, LS_LAYER_KC>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
+    else ls_tile<HP, LAST, TG, UT, false>(P, L, layer, in_buf, us, g_base + tq * TG, s_ab);
 }

@@ -32,7 +32,9 @@ static hipError_t ls_enqueue(azg_engine* e, hipStream_t main) {
     auto tkh = ls_hidden_tiled_kernel<HP, false, 2, 4>;
     auto tkl = ls_hidden_tiled_kernel<HP, true, 2, 4>;
     const int TQ_all = (G + 1) / 2, NU = HP / 64;
-    const size_t tiled_bytes = (size_t)2 * (4 + 2) * LS_KC * 64 * 16;   // two stages of A (4 tiles) + B (2 groups)
+    // two stages of A (4 tiles) + B (2 groups); the weights-direct tile stages the activations only (and passes the head chain through
+    // the first TG * 64 entries)
+    const size_t tiled_bytes = LS_LAYER_WD ? (size_t)2 * 2 * LS_LAYER_KC * 64 * 16 : (size_t)2 * (4 + 2) * LS_KC * 64 * 16;
     const bool tiled = e->opt.ls_tiled != 0;
     if (tiled) {
         hipError_t rc = hipFuncSetAttribute((const void*)tkh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_bytes);
