@@ -28,6 +28,20 @@ __global__ __launch_bounds__(256, MINB) void probe4(KParams P, LockStep L, int i
         }
 }
 
+// the product's tile since round 5: weights straight into the owning wave's registers, only the activations staged (ls_tile_wd)
+template <int MINB, int TG, int KC>
+__global__ __launch_bounds__(256, MINB) void probe4wd(KParams P, LockStep L, int iters, int TQ) {
+    extern __shared__ f32x4 s_ab[];
+    const int NU = 16;
+    const int x = blockIdx.x % 8, j = blockIdx.x / 8, sp = NU / 8;
+    const int tq = j / sp, us = x * sp + j % sp;
+    for (int it = 0; it < iters; ++it)
+        for (int l = 1; l <= 3; ++l) {
+            ls_tile_wd<1024, false, TG, false, KC>(P, L, l, (l - 1) & 1, us, TG * (tq % TQ), s_ab);
+            __syncthreads();
+        }
+}
+
 template <int MINB>
 __global__ __launch_bounds__(256, MINB) void probe4dma(KParams P, LockStep L, int iters, int TQ) {
     extern __shared__ f32x4 s_ab[];
@@ -114,6 +128,21 @@ int main(int argc, char** argv) {
         run4(probe4<2, 1>, "   the same without global loads in the loop");
         run4(probe4<2, 3>, "   ... and without staging stores and barriers");
         run4(probe4<2, 7>, "   ... and without LDS operand reads (MFMAs only)");
+        auto runwd = [&](auto kern, int tg, int kc, int per_cu, const char* name) {
+            const size_t ldsw = (size_t)(2 * tg * kc * 64) * 16 < 16384 ? 16384 : (size_t)(2 * tg * kc * 64) * 16;
+            const int teams = 256 * per_cu / 16, tqn = teams / tqdiv > 0 ? teams / tqdiv : 1;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            CK(hipEventRecord(e0)); hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(256), ldsw, 0, P, L, iters, tqn > G / tg ? G / tg : tqn); CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) report(name, 256.0 * per_cu * iters * 3 * 2.0 * 16 * tg * 64 * 1024, ms);
+        };
+        runwd(probe4wd<2, 2, 2>, 2, 2, 1, "ls_tile_wd 32x64, chunks of 2, 1 workgroup per CU");
+        runwd(probe4wd<2, 2, 2>, 2, 2, 2, "ls_tile_wd 32x64, chunks of 2, 2 workgroups per CU");
+        runwd(probe4wd<2, 2, 4>, 2, 4, 2, "ls_tile_wd 32x64, chunks of 4, 2 workgroups per CU");
+        runwd(probe4wd<3, 2, 2>, 2, 2, 3, "ls_tile_wd 32x64, chunks of 2, 3 workgroups per CU");
+        runwd(probe4wd<2, 4, 2>, 4, 2, 1, "ls_tile_wd 64x64, chunks of 2, 1 workgroup per CU");
+        runwd(probe4wd<2, 4, 2>, 4, 2, 2, "ls_tile_wd 64x64, chunks of 2, 2 workgroups per CU");
+        runwd(probe4wd<3, 4, 2>, 4, 2, 3, "ls_tile_wd 64x64, chunks of 2, 3 workgroups per CU");
         // 8 waves, 64 x 64, one per CU (1024 trees)
         {
             const size_t ldsd = (size_t)LS_DMA_STAGE_F4(LS_KC) * 16;

@@ -16,7 +16,8 @@ if [ -f alphazero_gym_amd/csrc/libazgym_hip_stampa.so ]; then
   python3 tools/phase_profile.py pendulum 4096 --phase-a > $OUT/${TAG}_phase_C_treeA.txt 2>&1
   python3 tools/phase_profile.py cartpole 4096 --phase-a > $OUT/${TAG}_phase_B_treeA.txt 2>&1
 fi
-python3 tools/team_profile.py 1024 > $OUT/${TAG}_team_profile.txt 2>&1
+TEAM_LIB=libazgym_hip_stampa.so python3 tools/team_profile.py 1024 > $OUT/${TAG}_team_profile.txt 2>&1
+TEAM_LIB=libazgym_hip_stampa.so python3 tools/team_profile.py 512 > $OUT/${TAG}_team_profile_alone.txt 2>&1
 # env step + observation of phase B with ONE stamp pair (a build that runs within a few per cent of the product): 8- and 4-wave kernels
 if [ -f alphazero_gym_amd/csrc/libazgym_hip_stampe.so ]; then
   ( echo "== product library"; python3 tools/quick_times.py C B; AZG_WAVES=4 python3 tools/quick_times.py C
@@ -29,7 +30,7 @@ if [ -x tools/probes/tile8/tile8_probe ]; then
   for d in 1 32; do echo "== activation blocks / $d"; tools/probes/tile8/tile8_probe 200 $d; done > $OUT/${TAG}_tile_probe.txt 2>&1
 fi
 # BASELINE shapes with the general kernels beside the compile-time specialised ones, same box
-( python3 tools/quick_times.py C B C8192 B8192 E E2048; AZG_NO_SPEC=1 python3 tools/quick_times.py C B C8192 B8192 ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_quick_times.txt
+( python3 tools/quick_times.py C B C8192 B8192 E X1536 E2048 E3072 X4096; AZG_NO_SPEC=1 python3 tools/quick_times.py C B C8192 B8192 ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_quick_times.txt
 # end-to-end learning on one GPU (examples/selfplay_train.py)
 python3 examples/selfplay_train.py --game CartPole-v0 --games 512 --n-rollouts 32 --iters 80 2>/dev/null | grep "^{" > $OUT/${TAG}_learning_cartpole.jsonl
 python3 examples/selfplay_train.py --game Pendulum-v1 --games 512 --n-rollouts 50 --iters 40 --steps-per-iter 200 --train-rows 16384 --batch-size 128 2>/dev/null | grep "^{" > $OUT/${TAG}_learning_pendulum.jsonl
