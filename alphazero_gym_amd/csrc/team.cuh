@@ -26,7 +26,8 @@
 // round 1).  Per step (tools/team_profile.py, 153k cycles = 64 us): the three tiles 104k (two workgroups per CU side by side:
 // 94 % of the matrix pipe's rate while they run), hand-off waits 21k (4 per step, across XCDs), tree phases + first layer
 // 21k.  The two workgroups of a CU (blocks b and b + 256: tools/team_census.py) belong to different teams; shifting one team
-// by half a step or gating it on its partner's progress did not pay (two tiles side by side take 35k cycles, one alone 24k:
+// by half a step (re-measured in round 5 with the weights-direct tile: 12.80 / 12.82 ms with a 30k / 60k-cycle head start against 12.81)
+// or gating it on its partner's progress did not pay (two tiles side by side take 35k cycles, one alone 24k:
 // running them together is the efficient state), nor did making the first layer inside the first hidden layer's staging
 // (+18k cycles per step) or as a team phase of MFMA tiles behind an observation hand-off (same time as the vector-ALU form
 // here, one hand-off more).
