@@ -497,6 +497,8 @@ __device__ __forceinline__ void ls_tile_wd(const KParams& P, const LockStep& L, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = us * 4 + wave;                   // this wave's unit tile
     const f32x4* W = P.Wl[layer - 1] + (size_t)tile * S4 * 64 + lane;   // k-block kb of it: W[kb * 64]
+    // (timing experiment, round 5: the activations through the L2 with plain loads -- stale data, wrong results -- 13.68 against 12.78 ms:
+    // they push the slices' weights out of the XCD's L2; the sc1 loads around it are the faster way as well as the coherent one)
     const TileMem<SC1> in(L.act[in_buf]), out(L.act[in_buf ^ 1], wt), parts(L.parts, wt);
     f32x4 aw[2][KC];                                  // the weights of two chunks (set = chunk index & 1)
     f32x4 rb[NLB];

@@ -222,6 +222,14 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
             out.store4(((size_t)(g0 + c / 16) * (HP / 16) + u / 16) * 64 + ((u % 16) / 4) * 16 + c % 16, act4<true>(P.act, acc));
         }
     };
+#ifdef TEAM_STAGGER   /* diagnostic builds: the second half of the grid (every CU's other workgroup) starts TEAM_STAGGER cycles late
+                         (round 5, 60k cycles: the same 12.8 ms and the same per-tile times, tools/team_profile.py) */
+    if ((blockIdx.x >= gridDim.x / 2) && tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)(TEAM_STAGGER)) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+#endif
     if (has_tree) tree_init_root<ENV, TLDS, TPW>(P, st, ts, cold, edge_W, action, tree, live, sub, tj, gtree, s_obs);
     __syncthreads();
     first_layer(true);
