@@ -473,6 +473,33 @@ def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
             np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
+def test_team_kernel_in_two_launches_gives_up_as_one(native, monkeypatch):
+    """A batch that runs as two team launches (4136 trees, 4x1024): with a spin limit of zero the first launch raises the abort flag, the
+    second one leaves at its first wait, and the engine redoes the whole search with the per-layer launches: identical results."""
+    import ctypes as C
+    kw = dict(env_id=2, mode=1, n_trees=4136, n_sims=6, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
+    desc = _capi.make_desc(3, [1024] * 4, 2, "elu")
+    blob = O.make_weights(34, 3, [1024] * 4, 2)
+
+    def run():
+        e = native.HipEngine(**kw)
+        e.set_weights(desc, blob)
+        e.search(e.synthetic_roots())
+        form = _kernel_form(e)
+        out = dict(e.results(), **e.dump_tree())
+        n = native.lib().azg_debug_team_fallbacks(C.c_void_p(e._h.value))
+        e.close()
+        return out, n, form
+
+    monkeypatch.delenv("AZG_TEAM_SPIN_LIMIT", raising=False)
+    want, n0, f0 = run()
+    monkeypatch.setenv("AZG_TEAM_SPIN_LIMIT", "0")
+    got, n1, f1 = run()
+    assert (n0, f0) == (0, 2) and (n1, f1) == (1, 1), (n0, f0, n1, f1)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
 def test_config_e_persistent_kernel_equals_lockstep(native, monkeypatch):
     """The same network and search on the one-launch kernel (AZG_FORCE_PERSISTENT=1; weights streamed from L2) on a smaller batch:
     identical trees to the lock-step path's, record for record."""
