@@ -44,6 +44,11 @@
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
+#ifndef TEAM_LDS_COLD
+#define TEAM_LDS_COLD 1         // the default form (32-tree teams, two workgroups per CU, trees of <= 255 records): the cold records, returns and actions in LDS
+#endif                          // too (the weights-direct tile left the room), written out once at the end of the search
+// bytes per tree of that: Cold[R] + edge_W[R] + action[R]
+__host__ __device__ inline size_t team_cold_bytes(int R) { return ((size_t)R * (64 + 8 + 4) + 15) / 16 * 16; }
 #ifndef TEAM_TILE_DBG
 #define TEAM_TILE_DBG 0          // timing experiments only (lockstep.cuh: ls_tile's DBG): wrong results
 #endif
@@ -179,6 +184,13 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         ts.hot = (Rec*)(P.hot + tb);
         ts.child = P.child + tb * P.Kp;
         ts.prior = P.prior + tb;
+    }
+    constexpr bool LDS_COLD = TEAM_LDS_COLD && HP == 1024 && TT == 32 && MINB == 2 && TLDS == TS_LDS8;   // (<= 255 records: 68 KB at most, two per CU)
+    if constexpr (LDS_COLD) {
+        char* cb = (char*)s_ab + team_tree_off(P.tab_n, P.n_sims, KC, TGN) + team_tree_bytes(P.R, CONT, TLDS) * TPW + team_cold_bytes(P.R) * (has_tree ? tj : 0);
+        cold = (Cold*)cb;
+        edge_W = (double*)(cb + (size_t)P.R * 64);
+        action = (float*)(cb + (size_t)P.R * 72);
     }
     TreeState st = {};
     // Is the whole team on one XCD?  Every workgroup reports its XCC_ID into two zero-initialised words of the team (max of id
@@ -326,6 +338,9 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
                     P.prior[tb + j] = ts.prior[j];
                 }
             }
+        }
+        if constexpr (LDS_COLD) {
+            for (int j = sub; j < st.nrec; j += 16) { P.cold[tb + j] = cold[j]; P.edge_W[tb + j] = edge_W[j]; P.action[tb + j] = action[j]; }
         }
     }
 #ifdef AZG_STAMPS

@@ -26,7 +26,8 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
     const int TQ = (G + TGN - 1) / TGN;   // (this launch: G tree groups from g_base)
-    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC, TGN) + (size_t)TPW * team_tree_bytes(e->R, CONT, TLDS);
+    const bool lds_cold = TEAM_LDS_COLD && HP == 1024 && TT == 32 && MINB == 2 && TLDS == TS_LDS8;
+    const size_t lds = team_tree_off(e->tab_n, e->cfg.n_sims, KC, TGN) + (size_t)TPW * (team_tree_bytes(e->R, CONT, TLDS) + (lds_cold ? team_cold_bytes(e->R) : 0));
     if ((lds + 1024) * MINB > 160 * 1024) return hipErrorNotReady;
     auto kern = ls_team_kernel<ENV, HP, GMM, TLDS, KC, MINB, SPEC, TT>;
     // (per device: the dynamic-LDS attribute belongs to the device's copy of the kernel)
