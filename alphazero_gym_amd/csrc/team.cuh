@@ -211,6 +211,8 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
     // observations in LDS (K = obs_dim <= 4: the same fma chain from the bias over k = 0..3 as the MFMA form, bit for bit), written
     // into the team's first activation buffer in the hidden layers' B-operand layout: the observations never travel and the
     // first layer costs no hand-off of its own.  Thread: tree slot tid / (256 / TPW), 8 consecutive units.
+    // (Round 5 measured the thread's first-layer weights and biases kept in registers for the whole search, 40 of them, instead of a
+    // round trip to L2 in front of every first layer: 12.71-12.75 against 12.71-12.72 ms -- the store drain behind it hides the loads.)
     const TileMem<true> act0(L.act[0], true);
     auto first_layer = [&](bool wt_now) {
         constexpr int TPT = 256 / TPW;                       // threads per tree
