@@ -313,6 +313,24 @@ def test_replay_buffer_fifo_and_last_batch_rule():
     assert sizes == [2, 3]   # the last batch absorbs the remainder (buffers.py:108-123)
 
 
+def test_env_observation_is_what_the_env_hands_out():
+    """search/mcts.py env_observation (the state the reference's nodes keep: `forward`'s stochasticity check, the batched `_row`) against
+    every env's own reset / step observation, for states off the origin."""
+    from alphazero_gym_amd.envs import make_game
+    from alphazero_gym_amd.search.mcts import env_observation, env_signature
+    for game, action in (("CartPole-v0", 1), ("MountainCar-v0", 2), ("Acrobot-v1", 0), ("Pendulum-v0", np.array([0.7])), ("Pendulum-v1", np.array([-1.2])),
+                         ("MountainCarContinuous-v0", np.array([0.4]))):
+        env = make_game(game)
+        env.seed(5)
+        env.reset()
+        for _ in range(3):
+            obs, _r, _done, _ = env.step(action)
+            env_id, st = env_signature(env)
+            got = env_observation(env_id, st)
+            assert got.dtype == np.float32 and got.shape == np.asarray(obs).shape, (game, got, obs)
+            np.testing.assert_allclose(got, np.asarray(obs, dtype=np.float32), rtol=0, atol=1e-7, err_msg=game)
+
+
 def test_helpers_and_config():
     np.testing.assert_allclose(stable_normalizer(np.array([1, 3]), 1.0), [0.25, 0.75])
     np.testing.assert_allclose(stable_normalizer(np.array([2.0, 4.0]), 2.0), [0.2, 0.8])
