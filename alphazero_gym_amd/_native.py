@@ -90,6 +90,7 @@ def lib():
         if ver != _capi.ABI_VERSION:
             raise NativeLibraryMissing(f"ABI version mismatch: library {ver}, binding {_capi.ABI_VERSION}")
         _lib.azg_math_selftest.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
+        _lib.azg_search_info.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -98,11 +99,38 @@ def fns():
     return _fns
 
 
+class AzgSearchInfo(C.Structure):
+    """include/azgym.h: azg_search_report (filled by azg_search_info)"""
+    _fields_ = [("struct_size", C.c_int32), ("kernel_form", C.c_int32), ("tree_storage", C.c_int32), ("lds_exit", C.c_int32), ("spec", C.c_int32),
+                ("waves", C.c_int32), ("groups", C.c_int32), ("tile_trees", C.c_int32),
+                ("team_trees", C.c_int32), ("team_per_cu", C.c_int32), ("team_parts", C.c_int32), ("team_fallbacks", C.c_int32),
+                ("max_records", C.c_int32), ("max_children", C.c_int32), ("last_ms", C.c_float), ("kernel_name", C.c_char * 192)]
+
+
+KERNEL_FORMS = {-1: "none", 0: "persistent", 1: "per_layer", 2: "team"}
+TREE_STORAGE = {0: "global", 1: "lds8", 2: "lds9"}
+LDS_EXIT = {0: "resident", 1: "records", 2: "children", 3: "lds_size", 4: "forced", 5: "not_applicable"}
+
+
 class HipEngine(_capi.Engine):
     """Batched MCTS engine on one MI355X."""
 
     def __init__(self, **kw):
         super().__init__(fns(), **kw)
+
+    def search_info(self):
+        """azg_search_info: what the last search ran as -- kernel form, where the trees lived and why, team-kernel fall-backs --
+        as a dict (the enums as words: KERNEL_FORMS / TREE_STORAGE / LDS_EXIT)."""
+        info = AzgSearchInfo()
+        info.struct_size = C.sizeof(AzgSearchInfo)
+        self._check(lib().azg_search_info(self._h, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in AzgSearchInfo._fields_ if k not in ("struct_size", "kernel_name")}
+        d["kernel_name"] = info.kernel_name.decode()
+        d["kernel_form_id"] = info.kernel_form
+        d["kernel_form"] = KERNEL_FORMS[info.kernel_form]
+        d["tree_storage"] = TREE_STORAGE[info.tree_storage]
+        d["lds_exit"] = LDS_EXIT[info.lds_exit]
+        return d
 
 
 def math_selftest(fn_id, x, device_id=0):

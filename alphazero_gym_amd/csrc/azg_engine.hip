@@ -74,13 +74,6 @@ static int ls_prepare(azg_engine* e) {
     if (e->ls_hp == e->HP) return AZG_OK;
     for (void* p : e->ls_allocs) (void)hipFree(p);
     e->ls_allocs.clear();
-    if (!e->ls_fork) {
-        if (hipEventCreateWithFlags(&e->ls_fork, hipEventDisableTiming) != hipSuccess) return fail(e, AZG_E_DEVICE, "hipEventCreate failed");
-        for (int p = 1; p < LS_MAX_PIPES; ++p)
-            if (hipStreamCreateWithFlags(&e->ls_streams[p], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&e->ls_join[p], hipEventDisableTiming) != hipSuccess)
-                return fail(e, AZG_E_DEVICE, "stream / event creation for the lock-step pipelines failed");
-    }
     // tree groups padded to a multiple of 4: the tiled layer kernel works on 4 groups per workgroup
     const size_t B = e->cfg.n_trees, G = ((B + TREES_PER_WG - 1) / TREES_PER_WG + 3) / 4 * 4, HP = e->HP;
     float* obsT; float *a0, *a1, *parts; LsTree* tr; LsLane* ln;
@@ -158,11 +151,6 @@ void azg_engine_destroy(azg_engine* e) {
     if (e->d_eval) (void)hipFree(e->d_eval);
     for (void* p : e->sp_allocs) (void)hipFree(p);
     for (void* p : e->ls_allocs) (void)hipFree(p);
-    for (int p = 0; p < LS_MAX_PIPES; ++p) {
-        if (e->ls_streams[p]) (void)hipStreamDestroy(e->ls_streams[p]);
-        if (e->ls_join[p]) (void)hipEventDestroy(e->ls_join[p]);
-    }
-    if (e->ls_fork) (void)hipEventDestroy(e->ls_fork);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -235,18 +223,13 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     e->opt.groups = env_digit("AZG_GROUPS", 0);
     { const char* v = getenv("AZG_TRACE_CAP"); const int t = v ? atoi(v) : 0; e->opt.trace_cap = t > 0 ? t : 0; }
     { const char* v = getenv("AZG_TILE_TREES"); const int t = v ? atoi(v) : 0; e->opt.tile_trees = (t == 16 || t == 8) ? t : 0; }
-    e->opt.ls_tiled = env_digit("AZG_LS_TILED", 1);
-    e->opt.ls_pipes = env_digit("AZG_LS_PIPES", 1);
-    e->opt.ls_fuse0 = env_digit("AZG_LS_FUSE0", 0);
     e->opt.ls_team = env_digit("AZG_LS_TEAM", 1);
     e->opt.team_wide = env_digit("AZG_TEAM_WIDE", 1);
     e->team_kc = 0; e->team_minb = 0; e->team_tt = 32;
     { const char* v = getenv("AZG_TEAM_TT"); e->opt.team_tt = v ? atoi(v) : 0; }
     { const char* v = getenv("AZG_TEAM_SPIN_LIMIT"); e->opt.team_spin_limit = v ? atol(v) : (1L << 23); }
     e->d_team_cnt = nullptr; e->team_cnt_bytes = 0; e->team_pending = 0; e->team_fallbacks = 0; e->team_search_idx = 0;
-    e->kernel_form = -1;
-    for (int p = 0; p < LS_MAX_PIPES; ++p) { e->ls_streams[p] = nullptr; e->ls_join[p] = nullptr; }
-    e->ls_fork = nullptr;
+    e->kernel_form = -1; e->lds_exit = 0; e->lds_warned = 0; e->last_search_idx = 0; e->ms_kept = 0.0f; e->ms_kept_valid = 0;
     e->carry_max = 0;
     e->h_res_block = nullptr; e->d_res_block = nullptr; e->res_bytes = 0;
     e->d_wblob = nullptr; e->d_wmap = nullptr; e->w_floats = 0; e->dist_nd = -1; e->dist_ncomp = -1;
@@ -585,7 +568,7 @@ static int set_weights_impl(azg_engine* e, const azg_mlp_desc* d, const float* b
     // hidden->hidden layers that fit the register file stay there for the whole search
     int nhh = d->n_hidden - 1;
     int regs = nhh * (HP * HP / 256);   // VGPRs per lane: each of the 4 waves holds a quarter of every layer
-    e->nreg = (nhh >= 1 && nhh <= 3 && regs <= 288) ? nhh : 0;
+    e->nreg = (nhh >= 1 && nhh <= 2 && regs <= 288) ? nhh : 0;   // (three and more hidden->hidden layers: streamed, any depth)
     // LayerNorm and the rare activations live in the weight-streaming kernels only (keeps the register-resident kernels lean)
     if (d->layernorm || (d->activation != AZG_ACT_RELU && d->activation != AZG_ACT_ELU)) e->nreg = 0;
     if (e->opt.force_stream_weights) e->nreg = 0;
@@ -628,6 +611,10 @@ int azg_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
     if (carry)
         for (int i = 0; i < B; ++i) {
             if (carry[i] < 0 || carry[i] > (1 << 30)) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
+            // MCTSContinuous never reuses a tree (no forward(): mcts.py:589-600 builds a fresh root for every search); its kernels' sqrt
+            // table ends at n_sims + 1
+            if (carry[i] != 0 && e->cfg.mode == AZG_MODE_CONTINUOUS)
+                return fail(e, AZG_E_INVALID, "root_n_carry: continuous searches start from a fresh root (no carried count)");
             if (carry[i] > cmax) cmax = carry[i];
         }
     ON_DEVICE(e);
@@ -650,6 +637,8 @@ int azg_search_resident(azg_engine* e) {
     if (!e->mlp_ready) return fail(e, AZG_E_STATE, "azg_set_weights has not been called");
     ON_DEVICE(e);
     e->P.search_idx = e->search_idx;
+    e->last_search_idx = e->search_idx;
+    e->ms_kept_valid = 0;
     e->P.publish = (e->publish_always || e->publish_once) ? 1 : 0;
     e->team_search_idx = e->search_idx;
     const bool lockstep = use_lockstep(e);
@@ -671,6 +660,14 @@ int azg_search_resident(azg_engine* e) {
     e->results_valid = e->kernel_form == 0 ? 1 : 0;   // the one-launch search kernel writes return_results in its epilogue
     e->published = (e->kernel_form != 0 || e->tree_lds == TS_GLOBAL || e->P.publish) ? 1 : 0;
     e->redo_ok = 1;
+    if (e->kernel_form == 0 && e->tree_lds == TS_GLOBAL && e->lds_exit != AZG_LDS_EXIT_FORCED && !e->lds_warned) {
+        e->lds_warned = 1;
+        static const char* why[] = {"", "more than 511 records per tree (n_sims + 2)", "more than 16 children per node (c_pw / kappa)",
+                                    "the workgroup's LDS plan exceeds the CU's 160 KB", ""};
+        if (!getenv("AZG_QUIET"))
+            fprintf(stderr, "azgym: the trees of this search do not fit LDS residency (%s): they are kept in global memory -- same results, "
+                            "slower tree walk (azg_search_info; once per engine)\n", why[e->lds_exit & 3]);
+    }
     return AZG_OK;
 }
 
@@ -699,6 +696,7 @@ int azg_last_search_ms(azg_engine* e, float* ms) {
         int trc = team_check(e);
         if (trc) return trc;
     }
+    if (e->ms_kept_valid) { *ms = e->ms_kept; return AZG_OK; }   // (azg_dump_tree re-ran the search since: the time of the search itself)
     HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
     return AZG_OK;
 }
@@ -822,13 +820,20 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
         if (!e->redo_ok)
             return fail(e, AZG_E_STATE, "the last search's trees were not written out and its inputs have changed since (self-play step, new "
                                         "roots or weights): dump right after the search, or set AZG_PUBLISH_TREES=1");
+        // (with the index THAT search ran under -- azg_set_search_index may have moved the counter since -- and without disturbing
+        // the counter or the timing of the search being inspected: azg_last_search_ms keeps reporting that search, not the re-run)
+        float ms_before = 0.0f;
+        HIPCHK(e, hipEventElapsedTime(&ms_before, e->ev0, e->ev1));
+        const uint32_t idx_now = e->search_idx;
         e->publish_once = 1;
-        e->search_idx -= 1;
+        e->search_idx = e->last_search_idx;
         int rc = azg_search_resident(e);
         e->publish_once = 0;
+        e->search_idx = idx_now;
         if (rc) return rc;
         HIPCHK(e, hipStreamSynchronize(e->stream));
         { int trc = team_check(e); if (trc) return trc; }
+        e->ms_kept = ms_before; e->ms_kept_valid = 1;
     }
     size_t B = e->cfg.n_trees, R = e->R;
     std::vector<RecL> hot(B * R);
@@ -864,28 +869,48 @@ int azg_dump_tree(azg_engine* e, int32_t* n_records, int32_t* parent, int32_t* e
     return AZG_OK;
 }
 
-// diagnostic: searches that the persistent team kernel gave up on and the per-layer launches redid
-int azg_debug_team_fallbacks(azg_engine* e) { return e ? e->team_fallbacks : -1; }
-// diagnostic: the form the last search ran in (engine_host.h: kernel_form)
-int azg_debug_kernel_form(azg_engine* e) { return e ? e->kernel_form : -1; }
-// diagnostic: the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture
-// head, waves, tree groups, trees per group, compile-time specialisation; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh); returns
-// the length written
-int azg_debug_kernel_name(azg_engine* e, char* buf, size_t n) {
-    if (!e || !buf || n == 0) return AZG_E_INVALID;
+// the kernel(s) of the last search as rocprofv3 names them (template arguments: ENV, HP, NREG, tree storage, mixture head, waves, tree
+// groups, trees per group, compile-time specialisation; team kernel: ..., staging chunk length, workgroups per CU -- see search_kernel.cuh / team.cuh)
+static int kernel_name(const azg_engine* e, char* buf, size_t n) {
     // (ENV = 0: the CartPole / MountainCar family, 5: Acrobot, 2: both Pendulum versions, 4: MountainCarContinuous)
     const int env = e->cfg.mode == AZG_MODE_DISCRETE ? (e->cfg.env_id == AZG_ENV_ACROBOT ? 5 : 0) : (e->cfg.env_id == AZG_ENV_MOUNTAINCAR_CONT ? 4 : 2);
     const char* gmm = (env != 0 && e->P.ncomp >= 2) ? "true" : "false";
-    int w = 0;
     switch (e->kernel_form) {
-        case 0: w = snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees, e->spec); break;
-        case 1: w = snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP); break;
-        case 2:
-            w = snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb, e->spec, e->team_tt);
-            break;
-        default: w = snprintf(buf, n, "(no search yet)");
+        case 0: return snprintf(buf, n, "search_kernel<%d, %d, %d, %d, %s, %d, %d, %d, %d>", env, e->HP, e->nreg, e->tree_lds, gmm, e->waves, e->groups, e->tile_trees, e->spec);
+        case 1: return snprintf(buf, n, "ls_tree_kernel<%d, ...> + ls_layer0_kernel + ls_hidden_tiled_kernel<%d, ...> per simulation step", env, e->HP);
+        case 2: return snprintf(buf, n, "ls_team_kernel<%d, %d, %s, %d, %d, %d, %d, %d>", env, e->HP, gmm, e->tree_lds, e->team_kc, e->team_minb, e->spec, e->team_tt);
+        default: return snprintf(buf, n, "(no search yet)");
     }
-    return w;
+}
+
+// include/azgym.h: what the last search ran as (kernel form, tree residency and why, team fall-backs)
+int azg_search_info(azg_engine* e, azg_search_report* info) {
+    if (!e || !info) return AZG_E_INVALID;
+    if (info->struct_size != (int32_t)sizeof(azg_search_report)) return fail(e, AZG_E_INVALID, "azg_search_info: struct_size mismatch");
+    if (e->searched && e->team_pending) {   // (an abandoned team search is redone before its form is reported)
+        ON_DEVICE(e);
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int trc = team_check(e);
+        if (trc) return trc;
+    }
+    memset(info, 0, sizeof(*info));
+    info->struct_size = (int32_t)sizeof(azg_search_report);
+    info->kernel_form = e->searched ? e->kernel_form : AZG_FORM_NONE;
+    info->max_records = e->R; info->max_children = e->Kmax;
+    info->team_fallbacks = e->team_fallbacks;
+    if (!e->searched) { kernel_name(e, info->kernel_name, sizeof(info->kernel_name)); info->lds_exit = AZG_LDS_RESIDENT; return AZG_OK; }
+    const bool persistent = e->kernel_form == 0;
+    info->tree_storage = persistent ? e->tree_lds : AZG_TREES_GLOBAL;
+    info->lds_exit = !persistent ? AZG_LDS_NOT_APPLICABLE : (e->tree_lds != TS_GLOBAL ? AZG_LDS_RESIDENT : e->lds_exit);
+    info->spec = e->spec;
+    if (persistent) { info->waves = e->waves; info->groups = e->groups; info->tile_trees = e->tile_trees; }
+    if (e->kernel_form == 2) { info->team_trees = e->team_tt; info->team_per_cu = e->team_minb; info->team_parts = e->team_parts; }
+    float ms = 0.0f;
+    int rc = azg_last_search_ms(e, &ms);
+    if (rc) return rc;
+    info->last_ms = ms;
+    kernel_name(e, info->kernel_name, sizeof(info->kernel_name));
+    return AZG_OK;
 }
 
 // diagnostic (-DAZG_STAMPS builds): per-wave cycle sums [n_workgroups*4][16]; returns the number of rows

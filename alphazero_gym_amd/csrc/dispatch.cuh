@@ -60,7 +60,7 @@ static hipError_t launch_g(azg_engine* e) {
 // every engine whose parameters differ, runs the general kernels (AZG_NO_SPEC=1 forces them: tests).
 template <int ENV, int HP, int NREG, int TLDS, int NW, int NG, int NT = 16>
 static hipError_t launch_t(azg_engine* e) {
-    if constexpr (EnvFamily<ENV>::CONT && NW == 4 && NT == 16) {
+    if constexpr (EnvFamily<ENV>::CONT && NW == 4 && NT == 16 && TLDS != TS_LDS9) {   // (mixture heads: LDS trees of up to 255 records, else global)
         if (e->P.ncomp >= 2) return launch_g<ENV, HP, NREG, TLDS, true, NW, NG>(e);
     }
     if constexpr (NREG == 1 && TLDS == TS_LDS8 && NT == 16 && ENV != AZG_ENV_ACROBOT) {
@@ -87,11 +87,17 @@ static hipError_t launch(azg_engine* e) {
     // (node counts: the root's is the largest, carried count + n_sims)
     int ts = TS_GLOBAL;
     const long nmax = (long)e->carry_max + ns + 2;
+    e->lds_exit = AZG_LDS_EXIT_CHILDREN;          // (what azg_search_info reports when the trees end up in global memory)
     if (e->Kp == 16) {
+        e->lds_exit = AZG_LDS_EXIT_RECORDS;
         if (e->R <= 255 && nmax < 65536) ts = TS_LDS8;
         else if (e->R <= 511 && nmax < 2048) ts = TS_LDS9;
+        if (ts != TS_GLOBAL) e->lds_exit = AZG_LDS_EXIT_SIZE;   // from here on only the CU's 160 KB can push them out
     }
-    if (e->opt.force_global_tree) ts = TS_GLOBAL;
+    // Trees of 256 .. 511 records stay in LDS (9-bit ids) for the squashed-Normal / discrete heads of networks up to 256 wide; the
+    // mixture head's and the wide networks' kernels exist for 8-bit ids and for global trees only (round 6: 32 instantiations fewer)
+    if (ts == TS_LDS9 && (HP >= 512 || e->P.ncomp >= 2)) { ts = TS_GLOBAL; e->lds_exit = AZG_LDS_EXIT_RECORDS; }
+    if (e->opt.force_global_tree) { ts = TS_GLOBAL; e->lds_exit = AZG_LDS_EXIT_FORCED; }
     // (Continuous mode only.  The discrete family's 8-wave shapes were measured slower than its 4-wave ones -- CartPole, 8192 trees,
     // 2x256: 1.03 ms against 0.99 ms per search, and they were the only kernels of the family that spilled registers -- and are gone.)
     if constexpr (HP == 256 && NREG == 1 && EnvFamily<ENV>::CONT) {
@@ -125,9 +131,11 @@ static hipError_t launch(azg_engine* e) {
         hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS8, 4, 1>(e);
         if (rc != hipErrorInvalidConfiguration) return rc;
     }
-    if (ts == TS_LDS9) {
-        hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS9, 4, 1>(e);
-        if (rc != hipErrorInvalidConfiguration) return rc;
+    if constexpr (HP < 512) {
+        if (ts == TS_LDS9) {
+            hipError_t rc = launch_t<ENV, HP, NREG, TS_LDS9, 4, 1>(e);
+            if (rc != hipErrorInvalidConfiguration) return rc;
+        }
     }
     return launch_t<ENV, HP, NREG, TS_GLOBAL, 4, 1>(e);
 }
@@ -136,16 +144,15 @@ static hipError_t launch(azg_engine* e) {
 template <int ENV>
 static hipError_t dispatch_small(azg_engine* e) {
     const int HP = e->HP, NR = e->nreg;
+    // (one or two hidden->hidden layers are kept in registers; deeper trunks stream their weights from L2: any depth)
     if (HP == 64) {
         if (NR == 1) return launch<ENV, 64, 1>(e);
         if (NR == 2) return launch<ENV, 64, 2>(e);
-        if (NR == 3) return launch<ENV, 64, 3>(e);
         return launch<ENV, 64, 0>(e);
     }
     if (HP == 128) {
         if (NR == 1) return launch<ENV, 128, 1>(e);
         if (NR == 2) return launch<ENV, 128, 2>(e);
-        if (NR == 3) return launch<ENV, 128, 3>(e);
         return launch<ENV, 128, 0>(e);
     }
     return hipErrorInvalidValue;

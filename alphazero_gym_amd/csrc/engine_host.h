@@ -19,19 +19,12 @@ struct EngineOptions {
     int trace_cap;             // AZG_TRACE_CAP=n: traces a discrete tree may run per simulation step (0: automatic)
     int no_spec;               // AZG_NO_SPEC=1: the general kernels where a compile-time specialised one exists (dispatch.cuh)
     int tile_trees;            // AZG_TILE_TREES=16|8: trees per 16-column MFMA tile of the small-network kernels (0: automatic)
-    int ls_tiled;              // AZG_LS_TILED=0: the 16-tree x 256-unit weight-streaming layer kernel of the lock-step path
-    // measured on MI355X at config E (tools/sweep_e.py): none of the three pays -- defaults off, kept for other shapes
-    int ls_pipes;              // AZG_LS_PIPES=n: n independent pipelines on n streams (2: +6 %, 4: +40 % time: kernels of
-                               // different queues do not share the chip well)
-    int ls_fuse0;              // AZG_LS_FUSE0=1: first layer in the tree kernel's tail (+3.6 %: 64 workgroups instead of 256);
-                               // (made inside the first hidden layer's operand staging it cost +1 %: removed)
     int ls_team;               // AZG_LS_TEAM=0: the per-layer launches instead of the persistent team kernel (team.cuh)
     int team_wide;             // AZG_TEAM_WIDE=0: only the first form of the team kernel, 32-tree teams at two workgroups per CU (batches beyond that
                                // then take the per-layer launches)
     int team_tt;               // AZG_TEAM_TT=32 / 64: only teams of that many trees (default 0: 32, and 64 for batches beyond two 32-tree workgroups per CU)
     long team_spin_limit;      // AZG_TEAM_SPIN_LIMIT=n: polls a team hand-off may wait before the launch gives up (tests: 0)
 };
-#define LS_MAX_PIPES 8
 #define AZG_MAX_DEVICES 64    // per-device caches of kernel attributes (host side)
 
 // Where every element of the engine's weight buffer comes from, for one network shape (azg_engine.hip: build_weight_map)
@@ -80,8 +73,6 @@ struct azg_engine {
     uint32_t sp_step_idx;
     int* d_sp_t; int* d_sp_episode; int* d_sp_fcnt; double* d_sp_ret; double* d_sp_fsum; float* d_sp_rows;
     std::vector<void*> sp_allocs;
-    hipStream_t ls_streams[LS_MAX_PIPES];   // [0] unused (the engine's stream)
-    hipEvent_t ls_fork, ls_join[LS_MAX_PIPES];
     unsigned* d_team_cnt; size_t team_cnt_bytes;   // team kernel: hand-off counters + abort word
     int team_pending;        // a team kernel has been launched since its abort word was last read
     int team_fallbacks;      // searches it gave up on (redone by the per-layer launches)
@@ -91,6 +82,8 @@ struct azg_engine {
     int team_kc, team_minb;  // the team kernel form of the last launch (chunk length, workgroups per CU)
     int launch_timed;        // the last search's launch recorded ev0 / ev1 itself (hipExtLaunchKernelGGL)
     int kernel_form;         // what the last search ran as: 0 search_kernel, 1 lock-step launches, 2 team kernel
+    int lds_exit;            // AZG_LDS_*: why the last search's trees were not LDS-resident (dispatch.cuh: launch)
+    int lds_warned;          // the one stderr line about it has been printed
     LockStep ls;             // lock-step path for wide networks (lockstep.cuh)
     std::vector<void*> ls_allocs;
     int ls_hp;
@@ -101,6 +94,8 @@ struct azg_engine {
     int published;           // the last search's trees are in global memory (global-tree / lock-step / team forms always are)
     int redo_ok;             // roots, carried counts and weights are still the ones the last search ran on: azg_dump_tree may re-run it
     float last_ms;
+    uint32_t last_search_idx;   // the search index the last search ran under (azg_dump_tree re-runs it with this one)
+    float ms_kept; int ms_kept_valid;   // kernel time of the last search, kept across azg_dump_tree's re-run of it
     std::string err;
 };
 
@@ -117,5 +112,7 @@ hipError_t azg_ls_dispatch_pendulum(azg_engine* e);
 // the same search as ONE persistent launch (team.cuh); hipErrorNotReady: its workgroups cannot all be resident, use the launches
 hipError_t azg_team_dispatch_cartpole(azg_engine* e);
 hipError_t azg_team_dispatch_pendulum(azg_engine* e);
+// the team kernel's forms for more than two 32-tree workgroups per CU (config E's network; team_dispatch.cuh); dry: residency check only
+hipError_t azg_team_wide_forms(azg_engine* e, int g_base, int G, bool dry, bool common, bool t32, bool t64);
 // batched network inference of n observations (device pointers) on e->stream (mlp_eval.cuh)
 hipError_t azg_dispatch_mlp_eval(azg_engine* e, const float* obs, int n, float* value, float* dist, float* raw);

@@ -128,15 +128,24 @@ __device__ __forceinline__ double discrete_env_terminal_reward(int env_id) {
     return env_id == AZG_ENV_CARTPOLE ? 1.0 : (env_id == AZG_ENV_ACROBOT ? 0.0 : -1.0);
 }
 
-// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node
-__device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {
-    const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
+// gym PendulumEnv.step; v1: speed clipped before integrating theta, v0: after.  sn_th = sin(theta), cached in the node.
+// Two halves that share nothing but their inputs -- the new state, and the reward (a function of the OLD state and the action only) --
+// so that a caller can take the reward later (tree_phases.cuh: DEFER); pendulum_step is both, in the order gym computes them.
+__device__ __forceinline__ double pendulum_torque(float action) {
     const float max_torque = 2.0f;
-    double th = s[0], thdot = s[1];
-    float uc = action < -max_torque ? -max_torque : (action > max_torque ? max_torque : action);
-    double u = (double)uc;
-    double an = azg_pymod(th + pi, 2.0 * pi, 0.15915494309189535) - pi;
-    double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
+    const float uc = action < -max_torque ? -max_torque : (action > max_torque ? max_torque : action);
+    return (double)uc;
+}
+__device__ __forceinline__ double pendulum_reward(const double* s, float action) {
+    const double pi = 3.141592653589793;
+    const double th = s[0], thdot = s[1], u = pendulum_torque(action);
+    const double an = azg_pymod(th + pi, 2.0 * pi, 0.15915494309189535) - pi;
+    const double costs = (an * an + 0.1 * (thdot * thdot)) + 0.001 * (u * u);
+    return -costs;
+}
+__device__ __forceinline__ void pendulum_dynamics(int v1, const double* s, double sn_th, float action, double* o) {
+    const double max_speed = 8.0, dt = 0.05, pi = 3.141592653589793;
+    const double th = s[0], thdot = s[1], u = pendulum_torque(action);
     double newth, newthdot, sn, cs;
     if (v1) {
         newthdot = thdot + (15.0 * sn_th + 3.0 * u) * dt;
@@ -149,6 +158,9 @@ __device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn
         newthdot = newthdot < -max_speed ? -max_speed : (newthdot > max_speed ? max_speed : newthdot);
     }
     o[0] = newth; o[1] = newthdot;
-    *reward = -costs;
+}
+__device__ __forceinline__ void pendulum_step(int v1, const double* s, double sn_th, float action, double* o, double* reward, int* done) {
+    *reward = pendulum_reward(s, action);
+    pendulum_dynamics(v1, s, sn_th, action, o);
     *done = 0;
 }

@@ -1,13 +1,10 @@
 // lockstep.cuh -- wide policy/value networks (hidden width >= 512; BASELINE config E: 4x1024): one simulation step = a few
 // grid-wide launches instead of one persistent kernel, so that a network layer of ALL trees is spread over ALL CUs.
 //   ls_tree_kernel     one workgroup per 16 trees: phase A (finish leaf, backup) + phase B (select, step, expand); trees and
-//                      the per-tree state live in global memory between launches.  (AZG_LS_FUSE0=1: also the first network layer
-//                      of the new leaves, from the observations it holds in LDS -- measured slower: 64 workgroups do what 256 did)
+//                      the per-tree state live in global memory between launches
 //   ls_layer0_kernel   first layer for (tree group, 256-unit slice)
 //   ls_hidden_tiled_kernel   one hidden->hidden layer as an LDS-tiled GEMM, 32 trees x 64 units per workgroup, both operands
 //                      double-buffered through LDS, two workgroups per CU; the last layer also leaves the partial head sums
-//   ls_hidden_kernel   the earlier form of that layer (16 trees x 256 units, weights streamed from L2 into registers), kept
-//                      behind AZG_LS_TILED=0
 // The arithmetic (MFMA chains, chunked head sums) is the persistent kernel's, bit for bit.
 #pragma once
 #include <type_traits>
@@ -18,14 +15,12 @@
 #include "tree.cuh"
 #include "tree_phases.cuh"
 
-// The batch can be cut into several independent pipelines (ranges of tree groups), each with its own launch sequence on its own
-// stream: one pipeline's tree kernel (few workgroups, latency-bound) then runs beside the other pipelines' layer kernels.
-// g_base = first tree group of the launching pipeline.  FUSE0: compute the first layer in this kernel's tail.
-template <int ENV, bool GMM, int NCH, int HP, bool FUSE0>
+// g_base = first tree group of the launch.  (Measured and removed, HISTORY.md: the earlier 16-tree x 256-unit weight-streaming layer
+// kernel; the first layer in this kernel's tail, +3.6 % time; the batch cut into pipelines on several streams, +6 % / +40 %.)
+template <int ENV, bool GMM, int NCH, int HP>
 __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int sim, int g_base) {
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2]
-    __shared__ float s_obs[64];         // [4][16] observations of the group's new leaves (FUSE0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane & 15;
     const int tl = wave * 4 + (lane >> 4);
     const int tg = g_base + blockIdx.x;
@@ -36,7 +31,6 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
     int* s_pw = (int*)(s_dyn + P.tab_n);
     for (int i = tid; i < P.tab_n; i += 256) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 256) s_pw[i] = P.pw_need[i];
-    if (FUSE0 && tid < 64) s_obs[tid] = 0.0f;   // a trace that ends on a terminal node leaves its column as it is: defined input
     __syncthreads();
     const size_t tb = (size_t)(live ? tree : 0) * P.R;
     Cold* cold = P.cold + tb;
@@ -46,7 +40,7 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
     ts.hot = P.hot + tb;
     ts.child = P.child + tb * P.Kp;
     ts.prior = P.prior + tb;
-    float* obsT = FUSE0 ? s_obs : L.obsT + (size_t)tg * 64;
+    float* obsT = L.obsT + (size_t)tg * 64;
     TreeState st;
     if (sim == -2) {
         tree_init_root<ENV, false>(P, st, ts, cold, edge_W, action, tree, live, sub, tl, gtree, obsT);
@@ -67,21 +61,6 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
             else if (sub < 4) obsT[sub * 16 + tl] = 0.0f;
         } else if (live && sub == 0) {
             P.n_rec[tree] = st.nrec;
-        }
-    }
-    if constexpr (FUSE0) {
-        if (sim < P.n_sims - 1) {
-            __syncthreads();
-            // first layer of the 16 new leaves: this wave's HP/64 output tiles, D = W0 (A operand) x obs (B operand) + b0
-            const float b = s_obs[lane];
-            f32x4* out = L.act[0] + (size_t)tg * (HP / 16) * 64;
-            constexpr int NT0 = HP / 64;
-#pragma unroll 4
-            for (int i = 0; i < NT0; ++i) {
-                const int tile = wave * NT0 + i;
-                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[tile * 64 + lane], b, P.b0[tile * 64 + lane], 0, 0, 0);
-                out[tile * 64 + lane] = act4<true>(P.act, acc);
-            }
         }
     }
     if (live) {
@@ -109,79 +88,6 @@ __global__ __launch_bounds__(256) void ls_layer0_kernel(KParams P, LockStep L, i
         const int tile = sl * 16 + wave * 4 + i;
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[tile * 64 + lane], b, P.b0[tile * 64 + lane], 0, 0, 0);
         out[tile * 64 + lane] = act4<true>(P.act, acc);
-    }
-}
-
-template <int HP, bool LAST>
-__global__ __launch_bounds__(256) void ls_hidden_kernel(KParams P, LockStep L, int layer, int in_buf, int g_base) {
-    constexpr int NS = HP / 256, S4 = HP / 16;
-    extern __shared__ f32x4 s_in[];   // the tree group's input activations: HP/16 tiles x 64 lanes
-    const int tg = g_base + blockIdx.x / NS, sl = blockIdx.x % NS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: weight addresses stay in SGPRs
-    const f32x4* bb = P.bl[layer - 1];
-    const int t0 = sl * 16 + wave * 4;   // this wave's 4 output tiles
-    const f32x4* W = P.Wl[layer - 1] + (size_t)t0 * S4 * 64 + lane;   // + (i * S4 + s4) * 64 with wave-uniform i, s4
-    // weight stream: DEPTH k-blocks (4 tiles x 16 B per lane each) are kept in flight per wave -- with one block in flight the
-    // loop ran at L2 latency (29 GB/s per CU), not at the matrix pipe's rate
-    constexpr int DEPTH = 8;
-    static_assert(S4 % DEPTH == 0, "k-blocks per layer must be a multiple of the prefetch depth");
-    f32x4 acc[4];   // bias first: loaded before everything that is still in flight inside the loop
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = bb[(t0 + i) * 64 + lane];
-    f32x4 q[DEPTH][4];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[d][i] = W[(i * S4 + d) * 64];
-    // stage the group's activations: all loads first (one round trip), then the LDS stores
-    const f32x4* in = L.act[in_buf] + (size_t)tg * S4 * 64;
-    constexpr int NST = S4 * 64 / 256;
-    f32x4 stg[NST];
-#pragma unroll
-    for (int i = 0; i < NST; ++i) stg[i] = in[i * 256 + tid];
-#pragma unroll
-    for (int i = 0; i < NST; ++i) s_in[i * 256 + tid] = stg[i];
-    __syncthreads();
-    // the bias has to have arrived before the loop: a wait for it inside the loop would, from the second pass on, wait for the
-    // weight blocks in flight instead (waitcnt placement is static)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i]));
-#pragma unroll 1
-    for (int s4 = 0; s4 < S4; s4 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const f32x4 b = s_in[(s4 + d) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].x, b.x, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].y, b.y, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].z, b.z, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[d][i].w, b.w, acc[i], 0, 0, 0);
-            // reload the same registers only after the MFMAs that read them: the new value's live range then does not overlap
-            // the old one's, the allocator keeps one register set and the loop has no copies (and no vmcnt(0)) at its end
-            const int sn = s4 + d + DEPTH < S4 ? s4 + d + DEPTH : S4 - 1;   // (the tail re-reads the last block: harmless)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[d][i] = W[(i * S4 + sn) * 64];
-            __builtin_amdgcn_sched_barrier(0);   // keep this block's loads here: the scheduler otherwise bunches all of an
-                                                 // iteration's loads at its end and the next iteration waits for them at once
-        }
-    }
-    f32x4 h[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = act4<true>(P.act, acc[i]);
-    if (!LAST) {
-        f32x4* out = L.act[in_buf ^ 1] + (size_t)tg * S4 * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[(t0 + i) * 64 + lane] = h[i];
-    } else {
-        // this wave's 64 units are one head chunk (chunk index = sl * 4 + wave): a chain from 0 over its 4 tiles
-        f32x4 hs = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hs = mfma4(P.Whead[(t0 + i) * 64 + lane], h[i], hs);
-        L.parts[((size_t)tg * (HP / 64) + sl * 4 + wave) * 64 + lane] = hs;
     }
 }
 

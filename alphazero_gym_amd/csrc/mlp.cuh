@@ -6,6 +6,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+
 // azg_expm1f on four values at once: the same operations in the same order per component (bit-identical), written
 // component-parallel so that the four dependent fma chains interleave (and pack into v_pk_fma_f32)
 __device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 xc) {
@@ -71,11 +72,12 @@ __host__ __device__ constexpr int head_chunks() { return HP <= 256 ? 8 : HP / 64
 
 // Register-resident hidden->hidden weights.  A workgroup has NW waves (4: 16 trees, 8: 32 trees = two groups of 16);
 // wave w owns output tiles [w*NTW, (w+1)*NTW) of each layer, for every tree group.
-template <int HP, int NREG, int NW = 4>
+// L0H: the first layer is computed by the workgroup's upper half of waves only (mlp_forward's SPLIT): they hold 2 * NTW tiles of it each.
+template <int HP, int NREG, int NW = 4, bool L0H = false>
 struct WRegs {
     static constexpr int NTW = HP / (16 * NW);
     static constexpr int S4 = HP / 16;
-    static constexpr int NW0 = HP <= 256 ? NTW : 1;   // first-layer weights are register-resident up to HP = 256
+    static constexpr int NW0 = HP <= 256 ? (L0H ? 2 * NTW : NTW) : 1;   // first-layer weights are register-resident up to HP = 256
     f32x4 w[NREG > 0 ? NREG : 1][NTW][S4];
     f32x4 b[NREG > 0 ? NREG : 1][NTW];
     f32x4 wh[NTW];   // head weights of this wave's K-chunk(s)
@@ -137,20 +139,49 @@ __device__ __forceinline__ void layer_norm_wg(const KParams& P, int layer, f32x4
 // NT: trees per group (16, or fewer: the remaining columns of the tile are fed zeros); obsT is then [4][NT*NG].
 // IN8: the kernel also serves networks with five to eight inputs (Acrobot: six observations): obsT is [8][NT*NG] and, when P.in8 says
 // so, the first layer takes a second k-step over input rows 4..7 (same accumulator: the k-ordered chain simply goes on).
-template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>, int NT = 16, bool IN8 = false>
+// SPLIT (eight waves, one group: search_kernel.cuh): the first layer of ALL tiles is computed by waves NW/2 .. NW-1 (twice NTW tiles each)
+// while waves 0 .. NW/2-1 -- the ones that walk the trees -- finish the bookkeeping of the node they have just created (tree_phase_b2);
+// the barrier behind the first layer is replaced by a counter in LDS (l0_flag, monotonic: `step` = number of this network phase, from 1),
+// so that the walking waves do not hold the others up: those arrive when their tiles are published and go on as soon as all NW/2 have,
+// the walking waves look at the counter when they get there.
+template <int HP, int NREG, int NW = 4, int NG = 1, int PSTR = 64, typename WR = WRegs<HP, NREG, NW>, int NT = 16, bool IN8 = false, bool SPLIT = false>
 __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, const float* obsT, f32x4* actA, f32x4* actB,
                                             f32x4* parts, float* s_ln, int wave, int lane
 #ifdef AZG_STAMPS
                                             , unsigned long long* st_acc
 #endif
-                                            ) {
-    STAMP(m0);
+                                            , int* l0_flag = nullptr, int step = 0) {
+    STAMP_M(m0, 4, -1);
+    static_assert(!SPLIT || (NW == 8 && NG == 1 && NT == 16 && HP <= 256 && NREG > 0 && !IN8), "split first layer: the eight-wave / 16-tree shape");
     constexpr int NTW = HP / (16 * NW);    // output tiles per wave
     constexpr int S4 = HP / 16;            // groups of 4 MFMA k-steps over a hidden vector
     constexpr int ABUF = HP / 16 * 64;     // float4 entries of one group's activation buffer
     constexpr int NCH = head_chunks<HP>();
     static_assert(NW == 4 || NREG > 0, "the weight-streaming path is written for 4 waves");
     f32x4 h[NG][NTW];                      // this wave's tiles of the latest layer, after the activation
+    if constexpr (SPLIT) {
+        constexpr int NT0 = 2 * NTW;       // first-layer tiles per computing wave
+        if (wave >= NW / 2) {
+            const float b = obsT[(lane >> 4) * 16 + (lane & 15)];
+            f32x4 a0[NT0];
+#pragma unroll
+            for (int i = 0; i < NT0; ++i) a0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr.w0[i], b, wr.b0[i], 0, 0, 0);
+            // (one branch around all tiles: their activation chains interleave)
+            if (P.act == AZG_ACT_ELU) {
+#pragma unroll
+                for (int i = 0; i < NT0; ++i) a0[i] = act4<false>(AZG_ACT_ELU, a0[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT0; ++i) a0[i] = act4<false>(AZG_ACT_RELU, a0[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NT0; ++i) actA[((wave - NW / 2) * NT0 + i) * 64 + lane] = a0[i];
+            // the tiles are in LDS before the arrival is counted (LDS executes a wave's operations in order; release for the compiler)
+            if (lane == 0) __hip_atomic_fetch_add(l0_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const int want = (NW / 2) * step;
+        while (__hip_atomic_load(l0_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+    } else {
     // layer 0: K = in_dim <= 4 -> one k-step
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -173,8 +204,24 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
                 a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0[nt * 64 + lane], b, P.b0[nt * 64 + lane], 0, 0, 0);
                 if constexpr (IN8) { if (P.in8) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(P.W0b[nt * 64 + lane], b2, a0, 0, 0, 0); }
             }
-            h[g][i] = act4<NREG == 0>(P.act, a0);
+            if constexpr (NREG == 0) h[g][i] = act4<true>(P.act, a0);   // (weight-streaming kernels: any activation)
+            else h[g][i] = a0;
         }
+    }
+    if constexpr (NREG > 0) {
+        // one branch around all of the wave's tiles: their activation chains interleave (register-resident kernels: ELU or ReLU)
+        if (P.act == AZG_ACT_ELU) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) h[g][i] = act4<false>(AZG_ACT_ELU, h[g][i]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) h[g][i] = act4<false>(AZG_ACT_RELU, h[g][i]);
+        }
+    }
     }
     // LayerNorm is compiled into the weight-streaming kernels only (the host selects them when layernorm is on)
     if constexpr (NREG == 0) { if (P.layernorm) layer_norm_wg<HP>(P, 0, h[0], s_ln, wave, lane); }
@@ -184,12 +231,14 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
     if (NREG > 0) {
 #pragma unroll
         for (int l = 0; l < NREG; ++l) {
+            if (!(SPLIT && l == 0)) {   // (SPLIT: the first layer's output is published and waited for above)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) buf[g * ABUF + (wave * NTW + i) * 64 + lane] = h[g][i];
-            __syncthreads();
-            STAMP(m1);
+                    for (int i = 0; i < NTW; ++i) buf[g * ABUF + (wave * NTW + i) * 64 + lane] = h[g][i];
+                __syncthreads();
+            }
+            STAMP_M(m1, 4, 5);
             f32x4 acc[NG][NTW];
             f32x4 bcur[NG], bnext[NG];
 #pragma unroll
@@ -226,12 +275,20 @@ __device__ __forceinline__ void mlp_forward(const KParams& P, const WR& wr, cons
 #pragma unroll
                 for (int g = 0; g < NG; ++g) bcur[g] = bnext[g];
             }
-            STAMP(m2);
+            STAMP_M(m2, 5, 6);
+            // one branch around all of the wave's tiles: their activation chains interleave (register-resident kernels: ELU or ReLU)
+            if (P.act == AZG_ACT_ELU) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) h[g][i] = act4<NREG == 0>(P.act, acc[g][i]);
-            STAMP(m2b);
+                    for (int i = 0; i < NTW; ++i) h[g][i] = act4<false>(AZG_ACT_ELU, acc[g][i]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) h[g][i] = act4<false>(AZG_ACT_RELU, acc[g][i]);
+            }
+            STAMP_M(m2b, 6, -1);
             if (l == 0) { STAMP_M_ADD(4, m0, m1); }
             STAMP_M_ADD(5, m1, m2);
             STAMP_M_ADD(6, m2, m2b);

@@ -134,27 +134,29 @@ struct LockStep {
 
 
 #ifdef AZG_STAMPS
-#ifdef AZG_STAMPS_ONLY_ENV   /* one stamp pair only -- around the env step + observation of tree phase B (slot 15) --, so that the build
-                                runs within a few per cent of the product's time (the full set of stamps costs the lean kernels 20 %) */
-#define STAMP(var)
-#define STAMP_ADD(slot, t0, t1)
-#define STAMP_ENV(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
-#define STAMP_ENV_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+/* -DAZG_STAMP_ONLY=<slot>: ONE stamp pair only, the one that feeds that slot, so that the build runs within a few per cent of the
+   product's time (the full set of stamps costs the lean kernels 20 %: read shares from the full set, cycles from the single pairs).
+   STAMP2(var, s1, s2): a time stamp that feeds slots s1 and s2 (-1: none). */
+#ifdef AZG_STAMP_ONLY
+#define STAMP_ON(s1, s2) ((s1) == (AZG_STAMP_ONLY) || (s2) == (AZG_STAMP_ONLY))
 #else
-#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
-#define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
-#define STAMP_ENV(var) STAMP(var)
-#define STAMP_ENV_ADD(slot, t0, t1) STAMP_ADD(slot, t0, t1)
+#define STAMP_ON(s1, s2) 1
 #endif
+#define STAMP3(var, s1, s2, s3) unsigned long long var = 0; if constexpr (STAMP_ON(s1, s2) || STAMP_ON(s3, s3)) { var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP2(var, s1, s2) STAMP3(var, s1, s2, -1)
+#define STAMP(var) STAMP2(var, -2, -2)
+#define STAMP_ADD(slot, t0, t1) do { if constexpr (STAMP_ON(slot, slot)) st_acc[slot] += (t1) - (t0); } while (0)
 #define STAMP_PARAM , unsigned long long* st_acc
 #define STAMP_ARG , st_acc
 #ifdef AZG_STAMPS_A   /* slots 4..6 = phase A's parts (finish leaf | backup | re-scoring) instead of the network's */
-#define STAMP_A(var) STAMP(var)
-#define STAMP_A_ADD(slot, t0, t1) do { if (st_acc) st_acc[slot] += (t1) - (t0); } while (0)
+#define STAMP_A(var, s1, s2) STAMP2(var, s1, s2)
+#define STAMP_A_ADD(slot, t0, t1) do { if constexpr (STAMP_ON(slot, slot)) { if (st_acc) st_acc[slot] += (t1) - (t0); } } while (0)
+#define STAMP_M(var, s1, s2) unsigned long long var = 0
 #define STAMP_M_ADD(slot, t0, t1)
 #else
-#define STAMP_A(var)
+#define STAMP_A(var, s1, s2)
 #define STAMP_A_ADD(slot, t0, t1)
+#define STAMP_M(var, s1, s2) STAMP2(var, s1, s2)
 #define STAMP_M_ADD(slot, t0, t1) STAMP_ADD(slot, t0, t1)
 #endif
 #define STAMP_PARAM_OPT , unsigned long long* st_acc = nullptr
@@ -162,11 +164,12 @@ struct LockStep {
 #define STAMP_PARAM
 #define STAMP_ARG
 #define STAMP(var)
+#define STAMP2(var, s1, s2)
+#define STAMP3(var, s1, s2, s3)
 #define STAMP_ADD(slot, t0, t1)
-#define STAMP_ENV(var)
-#define STAMP_ENV_ADD(slot, t0, t1)
-#define STAMP_A(var)
+#define STAMP_A(var, s1, s2)
 #define STAMP_A_ADD(slot, t0, t1)
+#define STAMP_M(var, s1, s2)
 #define STAMP_M_ADD(slot, t0, t1)
 #define STAMP_PARAM_OPT
 #endif

@@ -17,6 +17,9 @@
 #include "tree.cuh"
 #include "tree_phases.cuh"
 #include "results.cuh"
+#ifndef AZG_DEFER
+#define AZG_DEFER 1   // eight-wave / 16-tree continuous kernels: the new node's bookkeeping behind the barrier, first layer by the non-walking waves (0: A/B builds)
+#endif
 
 // Dynamic LDS layout of a workgroup, shared by the kernel and the host's launch planning
 struct LdsLayout {
@@ -64,6 +67,13 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     __shared__ float s_bhead[16];
     __shared__ float s_ln[NREG == 0 ? 2 * 64 : 1];
     __shared__ int s_done;              // discrete mode: trees of this workgroup that have finished their last trace
+    // DEFER (eight waves, one 16-tree group, Pendulum family, LDS trees): a simulation step's critical path is network phase -> finish leaf +
+    // backup -> descent -> action -> env step -> OBSERVATION.  Everything else phase B does for the node it creates -- edge and node records,
+    // the parent's child list, the reward, the cold record -- waits until after the barrier in front of the network phase and is then
+    // done by the walking waves (tree_phase_b2) WHILE the other four waves compute the first layer of all sixteen tiles (mlp_forward's
+    // SPLIT; a counter in LDS instead of the barrier behind that layer, so that nobody waits for the walking waves there).
+    constexpr bool DEFER = AZG_DEFER && NW == 8 && NG == 1 && ENV == AZG_ENV_PENDULUM_V1 && TLDS != TS_GLOBAL && NREG > 0 && !GMM && HP <= 256;
+    __shared__ int s_l0;                // (DEFER) first-layer tiles published so far, all network phases of the search
     extern __shared__ double s_dyn[];   // sqrt_tab [tab_n], pw_need [n_sims+2] u16, activation buffers, (TLDS) the trees' hot records
 
     const int tid = threadIdx.x;
@@ -82,12 +92,22 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     for (int i = tid; i < P.tab_n; i += 64 * NW) s_sqrt[i] = P.sqrt_tab[i];
     if (CONT) for (int i = tid; i < P.n_sims + 2; i += 64 * NW) s_pw[i] = (unsigned short)(P.pw_need[i] < 65535 ? P.pw_need[i] : 65535);
     if (tid < 16) s_bhead[tid] = P.bhead[tid];
-    if (tid == 0) s_done = 0;
+    if (tid == 0) { s_done = 0; s_l0 = 0; }
 
     // register-resident weights
-    WRegs<HP, NREG, NW> wr;
+    typedef WRegs<HP, NREG, NW, DEFER> WR;
+    WR wr;
     constexpr int NTW = HP / (16 * NW);
-    if constexpr (HP <= 256) {
+    if constexpr (DEFER) {
+        // (the first layer belongs to waves NW/2 .. NW-1, 2 * NTW tiles each: mlp_forward's SPLIT)
+        if (wave >= NW / 2) {
+#pragma unroll
+            for (int i = 0; i < 2 * NTW; ++i) {
+                wr.w0[i] = P.W0[((wave - NW / 2) * 2 * NTW + i) * 64 + lane];
+                wr.b0[i] = P.b0[((wave - NW / 2) * 2 * NTW + i) * 64 + lane];
+            }
+        }
+    } else if constexpr (HP <= 256) {
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             wr.w0[i] = P.W0[(wave * NTW + i) * 64 + lane];
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
 #endif
     TreeState st = {};
     st.need_eval = false;
+    BDeferred bdef = {};   // (DEFER: what the last phase B left for tree_phase_b2)
     if (cx.has_tree) tree_init_root<ENV, TLDS, TPW, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tree, cx.live, cx.sub, cx.tl, cx.gtree, s_obsT);
     __syncthreads();
 
@@ -170,12 +191,22 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
     // discrete kernels normally leave through s_done long before)
     for (int sim = -1; sim < P.n_sims; ++sim) {
         // ================= network phase: evaluate the pending leaves =================
-        STAMP(t_a);
+        STAMP2(t_a, 0, -1);
         // one barrier: the observations of phase B are visible.  The network runs even if every pending leaf of the workgroup is
         // terminal (rare; its outputs are then ignored): testing for that costs two more barriers per step (__syncthreads_or)
         __syncthreads();
         if constexpr (MULTI) { if (*(volatile int*)&s_done >= n_live) break; }   // (uniform: nobody adds to s_done before the network phase's barriers)
-        STAMP(t_b);
+        STAMP2(t_b, 0, 1);
+        if constexpr (DEFER) {
+            // the rest of the node phase B has just created (the other waves are in the first layer meanwhile)
+            STAMP2(t_b2a, 12, -1);
+            if (cx.live) tree_phase_b2<ENV, TLDS, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, bdef, cx.sub);
+            bdef.pending = false;
+            STAMP2(t_b2b, 12, -1);
+#ifdef AZG_STAMP_ONLY
+            STAMP_ADD(12, t_b2a, t_b2b);   // (single-pair builds only: slot 12 counts descent levels in the full set)
+#endif
+        }
         unsigned pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;
         int tid_o = tid;
         if constexpr (LEAN) {
@@ -187,11 +218,11 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3));
         }
 #ifdef AZG_STAMPS
-        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT, IN8>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WR, NT, IN8, DEFER>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, st_acc, &s_l0, sim + 2);
 #else
-        mlp_forward<HP, NREG, NW, NG, PSTR, WRegs<HP, NREG, NW>, NT, IN8>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane);
+        mlp_forward<HP, NREG, NW, NG, PSTR, WR, NT, IN8, DEFER>(P, wr, s_obsT, s_actA, s_actB, s_parts, s_ln, wave, lane, &s_l0, sim + 2);
 #endif
-        STAMP(t_c);
+        STAMP2(t_c, 1, 2);
         if constexpr (LEAN) {
             // opaque to the optimiser: whatever is derived from these is computed HERE, not kept alive across the network phase
             asm volatile("" : "+v"(pk0), "+v"(pk1), "+v"(pk2), "+v"(pk3), "+v"(tid_o));
@@ -211,13 +242,13 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             // ================= tree phase A: finish the evaluated leaf, back up =================
             if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
             if (sim == P.n_sims - 1) break;
-            __threadfence_block();
-            STAMP(t_d);
+            tree_fence();
+            STAMP2(t_d, 2, 3);
             // ================= tree phase B: next trace: select down, step the env, expand =================
             st.need_eval = false;
-            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
-            __threadfence_block();
-            STAMP(t_e);
+            if (cx.live) tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC, IN8, DEFER>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG, &bdef);
+            tree_fence();
+            STAMP2(t_e, 3, -1);
             STAMP_ADD(2, t_c, t_d);   // finish leaf + backup
             STAMP_ADD(3, t_d, t_e);   // select / step / expand
         } else {
@@ -225,10 +256,10 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             bool run = cx.live && my_sim < P.n_sims;
             int k = 0;
             while (run) {
-                STAMP(t_c2);
+                STAMP2(t_c2, 2, -1);
                 tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
-                __threadfence_block();
-                STAMP(t_d);
+                tree_fence();
+                STAMP2(t_d, 2, 3);
                 st.need_eval = false;
                 if (my_sim == P.n_sims - 1) {
                     my_sim = P.n_sims;                          // the tree's last trace is backed up
@@ -237,11 +268,11 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
                 } else {
                     my_sim += 1;
                     tree_phase_b<ENV, TLDS, GMM, TPW, unsigned short, !LEAN, !CONT, SPEC, IN8>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, cx.sub, cx.tl, cx.gtree, s_sqrt, s_pw, s_obsT STAMP_ARG);
-                    __threadfence_block();
+                    tree_fence();
                     k += 1;
                     if (st.need_eval || k >= P.trace_cap) run = false;
                 }
-                STAMP(t_e);
+                STAMP2(t_e, 3, -1);
                 STAMP_ADD(2, t_c2, t_d);   // finish leaf + backup
                 STAMP_ADD(3, t_d, t_e);    // select / step / expand
             }

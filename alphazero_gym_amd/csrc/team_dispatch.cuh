@@ -19,9 +19,9 @@
 
 // One variant: hipErrorNotReady when its workgroups cannot all be resident at once (or the shape is not its).
 // wider_form_exists: a form built for more workgroups per CU follows for this shape, so this one takes batches of up to MINB per CU only;
-// otherwise it takes whatever the occupancy query allows (up to 6).
+// otherwise it takes whatever the occupancy query allows (up to 6).  dry: check only, launch nothing.
 template <int ENV, int HP, bool GMM, int TLDS, int KC, int MINB, int SPEC = 0, int TT = 32>
-static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_base, int G) {
+static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_base, int G, bool dry = false) {
     constexpr int NU = HP / 64, TPW = TT / NU, TGN = TT / 16;
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     if (e->n_hidden - 1 >= TEAM_CNT_XB) return hipErrorNotReady;   // (one counter per hidden layer)
@@ -50,6 +50,7 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_
     int usable = per_cu < 6 ? per_cu : 6;
     if (wider_form_exists && usable > MINB) usable = MINB;   // (the next form takes the larger batches)
     if (usable < 1 || (long)TQ * NU > (long)usable * e->n_cus) return hipErrorNotReady;
+    if (dry) return hipSuccess;   // (residency check only: team_launch asks about every part of a two-part search before it launches the first)
     hipError_t rc = g_base == 0 ? hipMemsetAsync(e->d_team_cnt, 0, e->team_cnt_bytes, e->stream) : hipSuccess;
     if (rc != hipSuccess) return rc;
     TeamCtl T;
@@ -74,22 +75,37 @@ static hipError_t team_launch_form(azg_engine* e, bool wider_form_exists, int g_
 //        launches: 38.2 ms)
 // AZG_TEAM_WIDE=0: the first form only; AZG_TEAM_TT=32 / 64: only teams of that size (A/B runs).
 template <int ENV, int HP, bool GMM, int TLDS>
-static hipError_t team_launch_part(azg_engine* e, int g_base, int G) {
+static hipError_t team_launch_part(azg_engine* e, int g_base, int G, bool dry = false) {
     constexpr bool WIDE = HP == 1024 && !GMM && TLDS == TS_LDS8 && ENV == AZG_ENV_PENDULUM_V1;
-    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, false, g_base, G);
+    if constexpr (!WIDE) return team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, false, g_base, G, dry);
     else {
         // (the BASELINE shape's tree phases compiled for the common parameter set -- dispatch.cuh: SPEC --; AZG_NO_SPEC=1: the general kernel)
         const bool common = e->cfg.epsilon == 0.0 && e->cfg.tie_break == AZG_TIE_FIRST && e->cfg.env_id == AZG_ENV_PENDULUM_V1 && !e->opt.no_spec;
         const bool wide = e->opt.team_wide != 0, t32 = e->opt.team_tt != 64, t64 = e->opt.team_tt != 32 && wide;
         hipError_t rc = hipErrorNotReady;
-        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2, 1>(e, wide, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, wide, g_base, G);
-        if (rc == hipErrorNotReady && t32 && wide) rc = team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32W, 3>(e, true, g_base, G);
-        // (64-tree teams: the long chunks' stages + four 200-simulation trees are 84 KB, two of that do not fit a CU; short chunks: 52 KB)
-        if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 1, 64>(e, true, g_base, G) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 0, 64>(e, true, g_base, G);
-        if (rc == hipErrorNotReady && t64) rc = team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 3, 0, 64>(e, false, g_base, G);
+        if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2, 1>(e, wide, g_base, G, dry) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32, 2>(e, wide, g_base, G, dry);
+        if (rc == hipErrorNotReady && wide) rc = azg_team_wide_forms(e, g_base, G, dry, common, t32, t64);   // (their own translation unit)
         return rc;
     }
 }
+
+// The forms for batches beyond two 32-tree workgroups per CU (BASELINE config E's network, LDS trees) live in their own translation unit,
+// dispatch_team_wide.hip, which is compiled with -mllvm -disable-machine-licm: with every loop-invariant constant and address hoisted out
+// of the simulation loop the three-per-CU forms spill (64-tree teams: 35 VGPRs, 140 B of scratch per lane; without the hoisting 6 / 24 B)
+// and run 1-3 % slower (1536 trees 18.05 -> 17.54 ms, 3072 trees 32.11 -> 31.82); the two-per-CU 32-tree form of config E itself is
+// 1.5 % FASTER with the hoisting (12.72 against 12.91 ms) and stays in dispatch_team.hip (MI355X, same box; profiles/r06_licm_ab.txt).
+#ifdef AZG_TEAM_WIDE_TU
+hipError_t azg_team_wide_forms(azg_engine* e, int g_base, int G, bool dry, bool common, bool t32, bool t64) {
+    constexpr int ENV = AZG_ENV_PENDULUM_V1, HP = 1024, TLDS = TS_LDS8;
+    constexpr bool GMM = false;
+    hipError_t rc = hipErrorNotReady;
+    if (t32) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32W, 3, 1>(e, true, g_base, G, dry) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC32W, 3>(e, true, g_base, G, dry);
+    // (64-tree teams: the long chunks' stages + four 200-simulation trees are 84 KB, two of that do not fit a CU; short chunks: 52 KB)
+    if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 1, 64>(e, true, g_base, G, dry) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 2, 0, 64>(e, true, g_base, G, dry);
+    if (rc == hipErrorNotReady && t64) rc = common ? team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 3, 1, 64>(e, false, g_base, G, dry) : team_launch_form<ENV, HP, GMM, TLDS, TEAM_KC64, 3, 0, 64>(e, false, g_base, G, dry);
+    return rc;
+}
+#endif
 
 // Batches beyond the widest form (3072 trees at HP = 1024) run as TWO launches of equal parts, one after the other on the engine's
 // stream (trees are independent; a launch's workgroups all have to be resident at once): 4096 trees 46.5 ms against 48.7 ms for the
@@ -104,7 +120,11 @@ static hipError_t team_launch(azg_engine* e) {
     if (!WIDE || G <= G_MAX || !e->opt.team_wide || e->opt.team_tt == 32) return team_launch_part<ENV, HP, GMM, TLDS>(e, 0, G);
     const int parts = (G + G_MAX - 1) / G_MAX, per = ((G + parts - 1) / parts + 3) / 4 * 4;   // (whole 64-tree teams)
     if (parts > 2) return hipErrorNotReady;
+    // both parts' residency (occupancy, LDS) is checked before the first one is launched: a second part that does not fit
+    // would otherwise send the whole search to another form behind an orphaned first launch
     hipError_t rc = hipSuccess;
+    for (int g = 0; g < G && rc == hipSuccess; g += per) rc = team_launch_part<ENV, HP, GMM, TLDS>(e, g, G - g < per ? G - g : per, true);
+    if (rc != hipSuccess) return rc;
     for (int g = 0; g < G && rc == hipSuccess; g += per) rc = team_launch_part<ENV, HP, GMM, TLDS>(e, g, G - g < per ? G - g : per);
     e->team_parts = parts;
     return rc;

@@ -2,6 +2,13 @@
 #pragma once
 #include "records.h"
 
+// A tree belongs to ONE wave: its records -- in LDS or in global memory -- are written and read by the lanes of that wave only, and a wave's
+// memory operations take effect in program order: what orders lane 0's record stores with the other lanes' later loads is a fence at
+// wavefront scope, which only stops the compiler from moving them (LLVM's AMDGPU memory model generates no instruction for it).  The
+// workgroup-scope fence that stood here until round 6 made the wave wait for every outstanding global store (s_waitcnt vmcnt(0)) twice per
+// simulation step.
+__device__ __forceinline__ void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
 // n / d for the tree statistics (n finite, d a positive count, both far from the ends of the exponent range): the compiler's own
 // IEEE float64 division sequence (v_rcp_f64, two Newton steps, quotient, residual correction) without its operand scaling
 // and fix-up steps, which are no-ops for such operands -- the same correctly rounded quotient in 8 instead of 11 instructions
@@ -215,7 +222,7 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
             if (!(at_leaf && sub == 0)) mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
             ts.hot[mine] = mrec;
         }
-        if (!TLDS) __threadfence_block();
+        if (!TLDS) tree_fence();
         for (int d = 0; d < cnt; ++d) {
             const int pn = __shfl(mine, d, 16);
             if (!(at_leaf && d == 0)) on_node(pn);   // (a trace's leaf has no selection to refresh)

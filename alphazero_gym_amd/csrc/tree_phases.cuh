@@ -244,7 +244,7 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
-    STAMP_A(ta0);
+    STAMP_A(ta0, 4, -1);
     if (st.need_eval) {
         // discrete mode: outputs 0..3 (value, logits) in one pass over the partials; continuous mode keeps three separate
         // sums (measured at config C: the one-pass form is 3 % slower there, at config B 10 % faster)
@@ -337,16 +337,16 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     const double o = dpp_f64<DPP_QUAD_XOR1>(U);
                     if (sub == 0) set_best<false>(&ts.hot[st.leaf], make_edge<Rec>(0.0, 0), U >= o ? 0 : 1);   // (index relative to first)
                 } else {
-                    if (!TLDS) __threadfence_block();
+                    if (!TLDS) tree_fence();
                     refresh_best<ENV, TLDS, SPEC>(P, ts, st.leaf, sub, s_sqrt);
                 }
             }
         }
     }
-    STAMP_A(ta1);
+    STAMP_A(ta1, 4, 5);
     STAMP_A_ADD(4, ta0, ta1);   // finish leaf
     if (sim >= 0) {
-        if (!TLDS) __threadfence_block();   // lane 0's partial record stores above must land before the path is re-read
+        if (!TLDS) tree_fence();   // lane 0's partial record stores above must land before the path is re-read
         const bool keep = !CONT && Spec<SPEC, ENV>::plain(P);   // (cached selections: discrete mode, see rec_best)
         Rec myrec;
         backup_path<CONT, TLDS>(ts, cold, edge_W, V, sub, P.gamma_f, P.gamma, st.path_D, st.my_depth, st.pid, st.pr, st.pW,
@@ -355,14 +355,14 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                                 CONT ? 0.0 : discrete_env_reward(Spec<SPEC, ENV>::env(P)),
                                 // (a pending leaf that needs no evaluation is a terminal node: need_eval = !done)
                                 CONT ? 0.0 : (st.need_eval ? discrete_env_reward(Spec<SPEC, ENV>::env(P)) : discrete_env_terminal_reward(Spec<SPEC, ENV>::env(P))));
-        STAMP_A(ta2);
+        STAMP_A(ta2, 5, 6);
         STAMP_A_ADD(5, ta1, ta2);   // backup (return chain, record updates)
         if constexpr (!CONT) {
             if (keep) {
                 // the selections of the path's nodes, with their new statistics: depths D-1 .. max(0, D-15) are in the lanes' slots
                 // (anything deeper than 16 levels was refreshed by backup_from through the callback above)
                 const int D = st.path_D, lo = D > 15 ? D - 15 : 0;
-                if (!TLDS) __threadfence_block();
+                if (!TLDS) tree_fence();
                 if (Spec<SPEC, ENV>::A(P) == 2) {
                     // (a slot holds a path node above the leaf: depth in [lo, D - 1]; a root that was never left is slot 0, depth 0)
                     const bool mine = st.my_depth >= lo && st.my_depth < D;
@@ -382,8 +382,56 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                 }
             }
         }
-        STAMP_A(ta3);
+        STAMP_A(ta3, 6, -1);
         STAMP_A_ADD(6, ta2, ta3);   // re-scoring of the path's nodes + where the next descent leaves the path
+    }
+}
+
+// DEFER (the eight-wave / 16-tree continuous kernels, search_kernel.cuh): what phase B leaves for tree_phase_b2 -- everything about the
+// new node that the network's next evaluation does not wait for.  The step's critical path ends with the new leaf's observation (the
+// barrier in front of the network phase); the new edge's and node's records, the parent's child list, the reward (a function of the
+// parent's state and the action only) and the cold record are written after that barrier, while the workgroup's non-walking waves
+// compute the first layer.
+struct BDeferred {
+    bool pending, widen;
+    int p, chosen;          // parent node, the new record
+    float cact;             // the action of the edge
+};
+
+// the deferred half of phase B (Pendulum family: the nodes never end an episode).  The parent's records are read again here (nothing
+// has touched them since the descent): carrying them across the barrier would cost the lean walkers registers they do not have.
+template <int ENV, int TLDS, int SPEC>
+__device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W, float* action,
+                                              const BDeferred& d, int sub) {
+    typedef typename TreeStore<TLDS>::Rec Rec;
+    static_assert(ENV == AZG_ENV_PENDULUM_V1, "deferred expansion: the Pendulum family");
+    if (!d.pending) return;
+    const double ps0 = cold[d.p].s[0], ps1 = cold[d.p].s[1];   // the parent's env state (reward)
+    if (d.widen) {
+        // MCTSContinuous.add_pw_action (mcts.py:625-654): the edge, with the node half filled in at once (flags)
+        const float V = cold[d.p].V;        // the parent's value: the new edge's Q_init
+        const Rec hp = ts.hot[d.p];
+        if (sub == 0) {
+            Rec h = make_edge<Rec>((double)V, d.p);
+            h.flags = FLAG_EXPANDED;
+            clear_pad(h);
+            ts.hot[d.chosen] = h;
+            edge_W[d.chosen] = 0.0;
+            action[d.chosen] = d.cact;
+        }
+        ts.child_append(d.p, hp, (int)hp.n_child, d.chosen, st.ptop, sub == 0, P.Kp);
+    } else if (sub == 0) {
+        ts.hot[d.chosen].flags = (unsigned char)FLAG_EXPANDED;
+    }
+    // MCTS.expansion (mcts.py:216-238): the reward of the step that led here (mcts.py:687: divided by PENDULUM_R_SCALE) and the rest of the
+    // node's cold record (phase B stored the env state)
+    const double sp[2] = {ps0, ps1};
+    const double r = pendulum_reward(sp, d.cact) / P.reward_scale;
+    if (sub == 0) {
+        float zero = 0.0f;
+        asm volatile("" : "+v"(zero));
+        Cold* c = cold + d.chosen;
+        c->s[3] = 0.0; c->r = r; c->V = zero; c->mu = zero; c->sg = zero; c->pad = zero;
     }
 }
 
@@ -392,10 +440,12 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 // FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
 // RESUME (discrete mode, cached selections): the descent starts where the last trace's path is left (st.resume, set by
 // tree_phase_a<..., RESUME = true>) instead of at the root; the path slots above that depth are still in the lanes.
-template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0, bool OBS8 = false>
+// DEFER: the new node's records, reward and cold record are left to tree_phase_b2 (`def`); the caller fetches st.pr later (FETCH = false).
+template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0, bool OBS8 = false, bool DEFER = false>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
-                                             const PW* s_pw, float* obsT STAMP_PARAM) {
+                                             const PW* s_pw, float* obsT STAMP_PARAM, BDeferred* def = nullptr) {
+    static_assert(!DEFER || (ENV == AZG_ENV_PENDULUM_V1 && !GMM && !FETCH), "deferred expansion: Pendulum family, squashed-Normal head, lean walkers");
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
@@ -434,9 +484,9 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         hit_terminal = resumed && (hp.flags & FLAG_TERMINAL);   // (the old trace ended in a terminal node and nothing moved)
         st.repeat = FETCH && hit_terminal;                       // the same trace again: same slots, same rewards, V = 0 both times
     }
-    STAMP(tb0);
+    STAMP2(tb0, 13, -1);
     while (!hit_terminal) {
-        STAMP(tl0);
+        STAMP3(tl0, 7, 8, 11);
         const int K = hp.n_child;
         if (CONT) {
             int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
@@ -454,9 +504,9 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         } else {
             chosen = rec_best<CONT>(hp);   // taken when the node's statistics last changed (refresh_best)
         }
-        STAMP(tl1);
+        STAMP2(tl1, 7, -1);
         STAMP_ADD(7, tl0, tl1);    // the level's selection
-        STAMP(tl2);
+        STAMP2(tl2, 8, 9);
         // continuous mode: the chosen child's cold record (its cached policy and env state: needed at once if the trace widens there)
         // is requested before the hot record's LDS round trip, not after it (an edge without a child node: a record of the tree all
         // the same, its contents unused)
@@ -464,7 +514,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if constexpr (CONT && EARLY_COLD) cn = cold[chosen];
         Rec hc = ts.hot[chosen];
         if (!(hc.flags & FLAG_EXPANDED)) break;   // an edge without a child node: expand it
-        STAMP(tl3);
+        STAMP2(tl3, 9, 10);
         st.path_D += 1;
         p = chosen;
         hp = hc;
@@ -484,16 +534,16 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         if (CONT) { if constexpr (EARLY_COLD) cp = cn; else cp = cold[p]; }
         else if (from_cold) { cp.s[0] = cold[p].s[0]; cp.s[1] = cold[p].s[1]; cp.s[2] = cold[p].s[2]; cp.s[3] = cold[p].s[3]; }
         // (LDS-resident env states: read once, below, for the node the trace leaves the tree from)
-        STAMP(tl4);
+        STAMP2(tl4, 10, 11);
         STAMP_ADD(8, tl0, tl2);    // whole selection of a level (scores + arg-max)
         STAMP_ADD(9, tl2, tl3);    // chosen record
         STAMP_ADD(10, tl3, tl4);   // path slot + cold prefetch issue
         STAMP_ADD(11, tl0, tl4);   // full level
-#if defined(AZG_STAMPS) && !defined(AZG_STAMPS_ONLY_ENV)
+#if defined(AZG_STAMPS) && !defined(AZG_STAMP_ONLY)
         st_acc[12] += 1;
 #endif
     }
-    STAMP(tb1);
+    STAMP2(tb1, 13, 14);
     STAMP_ADD(13, tb0, tb1);       // whole descent
     if (hit_terminal) {
         st.leaf = p;
@@ -513,26 +563,34 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                 gmm_pick(gd, P.ncomp, P.seed, gtree, P.search_idx, (unsigned)chosen, &wmu, &wsg);
             }
             cact = P.bound_f * azg_tanhf(wmu + wsg * eps);
-            if (sub == 0) {
-                Rec h = make_edge<Rec>((double)cp.V, p);
-                clear_pad(h);
-                ts.hot[chosen] = h;
-                edge_W[chosen] = 0.0;
-                action[chosen] = cact;
+            if constexpr (!DEFER) {
+                if (sub == 0) {
+                    Rec h = make_edge<Rec>((double)cp.V, p);
+                    clear_pad(h);
+                    ts.hot[chosen] = h;
+                    edge_W[chosen] = 0.0;
+                    action[chosen] = cact;
+                }
+                ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
             }
-            ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
         }
         // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
-        STAMP_ENV(tw1);
+        STAMP2(tw1, 14, 15);
         STAMP_ADD(14, tb1, tw1);   // widening (noise, policy parameters, tanh, edge record, child list)
         st.path_D += 1;
         double ns[S], r, sn;
         int done;
         if (CONT) {
             if (!widen) cact = action[chosen];
-            if constexpr (ENV == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(cp.s, cact, ns, &r, &done);
-            else pendulum_step(Spec<SPEC, ENV>::v1(P), cp.s, cp.s[2], cact, ns, &r, &done);
-            r = r / P.reward_scale;   // mcts.py:687 (whatever the env: the reference divides every continuous reward by PENDULUM_R_SCALE)
+            if constexpr (DEFER) {
+                // (the new state only: the reward is tree_phase_b2's)
+                pendulum_dynamics(Spec<SPEC, ENV>::v1(P), cp.s, cp.s[2], cact, ns);
+                r = 0.0; done = 0;
+            } else {
+                if constexpr (ENV == AZG_ENV_MOUNTAINCAR_CONT) mountaincar_cont_step(cp.s, cact, ns, &r, &done);
+                else pendulum_step(Spec<SPEC, ENV>::v1(P), cp.s, cp.s[2], cact, ns, &r, &done);
+                r = r / P.reward_scale;   // mcts.py:687 (whatever the env: the reference divides every continuous reward by PENDULUM_R_SCALE)
+            }
         } else {
             if constexpr (TLDS != TS_GLOBAL) {
                 if (ts.state) {
@@ -546,9 +604,12 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         float obs[OBS8 ? 8 : 4];
         if constexpr (OBS8) { sn = 0.0; azg_acrobot_obs(ns, obs); obs[6] = 0.0f; obs[7] = 0.0f; }
         else env_obs<ENV == AZG_ENV_ACROBOT ? AZG_ENV_CARTPOLE : ENV>(ns, obs, &sn);
-        STAMP_ENV(tw2);
-        STAMP_ENV_ADD(15, tw1, tw2);   // env step + observation
-        if (sub == 0) {
+        STAMP2(tw2, 15, -1);
+        STAMP_ADD(15, tw1, tw2);   // env step + observation
+        if constexpr (DEFER) {
+            def->pending = true; def->widen = widen; def->p = p; def->chosen = chosen; def->cact = cact;
+            if (sub == 0) { cold[chosen].s[0] = ns[0]; cold[chosen].s[1] = ns[1]; cold[chosen].s[2] = sn; }   // (the rest of the record: tree_phase_b2)
+        } else if (sub == 0) {
             Cold c;
 #pragma unroll
             for (int k = 0; k < 4; ++k) c.s[k] = k < S ? ns[k] : 0.0;

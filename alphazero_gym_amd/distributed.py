@@ -35,24 +35,31 @@ def unpack_replay_rows(rows: torch.Tensor, state_dim: int, K: int):
     return s, a, c, q, r[:, -1]
 
 
-def gather_replay_rows(rows: torch.Tensor, device=None, counts=None, total: int = None) -> torch.Tensor:
+def gather_replay_rows(rows: torch.Tensor, device=None, counts=None, total: int = None, rows_per_game: int = None) -> torch.Tensor:
     """All-gather the per-rank row blocks into [B_total, row] ordered by rank (= by global tree id).
 
-    The block lengths are known without asking anybody when the rows are one per game of a `shard_range` partition: pass
-    `total` (games of the whole job; rows per game are inferred from this rank's block) or `counts` (rows of every rank).
-    Equal blocks -- config D, the common case -- then cost ONE collective into one tensor, no padding, no host sync.  Only when
-    neither is given are the lengths exchanged first (one small all-gather + a host read per rank).  Blocks that differ in length
-    (by at most one game when `total` is not a multiple of the world size) are padded to the longest for the collective."""
+    The block lengths are known without asking anybody in two cases: `counts` (rows of every rank, the same list on every rank), or
+    `total` + `rows_per_game` -- `total` games of the WHOLE JOB partitioned by `shard_range`, `rows_per_game` rows for each of them
+    (1 for one search per game, n_steps for a block of self-play steps): rank r then holds (games of r) x rows_per_game rows, a rank
+    without games holds none.  Equal blocks -- config D, the common case -- then cost ONE collective into one tensor, no padding, no
+    host sync.  `total` without `rows_per_game` infers the latter from this rank's own block, which is only defined when EVERY rank
+    holds at least one game and the same number of rows per game: a precondition on the caller, checked on each rank against its own
+    block only (a rank that fails it raises while the others wait in the collective until the process group's timeout).
+    When neither is given the lengths are exchanged first (one small all-gather + a host read per rank): any shapes.
+    Blocks that differ in length are padded to the longest for the collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
     rows = (rows.to(device) if device is not None else rows).contiguous()
     if counts is None and total is not None:
-        lo, hi = shard_range(total, dist.get_rank(), world)
-        per_game, rem = divmod(rows.shape[0], max(hi - lo, 1))
-        if hi - lo == 0 or rem:
-            raise ValueError(f"rank {dist.get_rank()} holds {rows.shape[0]} rows for {hi - lo} games of {total}")
-        counts = [(b - a) * per_game for a, b in (shard_range(total, r, world) for r in range(world))]
+        spans = [shard_range(total, r, world) for r in range(world)]
+        if rows_per_game is None:
+            lo, hi = spans[dist.get_rank()]
+            rows_per_game, rem = divmod(rows.shape[0], max(hi - lo, 1))
+            if hi - lo == 0 or rem:
+                raise ValueError(f"rank {dist.get_rank()} holds {rows.shape[0]} rows for {hi - lo} games of {total}: pass rows_per_game "
+                                 "(or counts) when a rank may be without games")
+        counts = [(b - a) * int(rows_per_game) for a, b in spans]
     if counts is None:
         n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
         got = [torch.zeros_like(n) for _ in range(world)]

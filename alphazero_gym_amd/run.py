@@ -150,6 +150,10 @@ class BatchedSelfPlay:
                                     c_uct=c_uct, gamma=gamma, epsilon=epsilon, c_pw=c_pw, kappa=kappa, V_target_policy=V_target_policy,
                                     action_bound=float(policy.action_bound), seed=seed, tree_id_base=base, device_id=device_id)
         else:
+            if not game.lower().startswith("cartpole"):
+                # (this host-stepped loop has vectorised numpy envs for CartPole, Pendulum and MountainCarContinuous only)
+                raise NotImplementedError(f"BatchedSelfPlay steps CartPole, Pendulum and MountainCarContinuous on the host; {game} plays "
+                                          "its own dynamics on the device: use DeviceSelfPlay")
             self.env = VecCartPole(n_games, seed=seed + rank)
             self.mcts = BatchedMCTS(policy, env_id=_capi.ENV_CARTPOLE, mode=_capi.MODE_DISCRETE, n_trees=n_games, n_rollouts=n_rollouts,
                                     c_uct=c_uct, gamma=gamma, epsilon=epsilon, num_actions=policy.num_actions,

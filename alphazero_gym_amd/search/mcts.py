@@ -89,6 +89,7 @@ class BatchedMCTS:
                                         epsilon=epsilon, num_actions=num_actions, c_pw=c_pw, kappa=kappa, v_target=V_target_policy,
                                         action_bound=action_bound, seed=seed, tree_id_base=tree_id_base, device_id=device_id)
         self._version = None
+        self._cliff_warned = False
         self.sync_weights()
 
     def sync_weights(self, force: bool = False) -> None:
@@ -101,6 +102,20 @@ class BatchedMCTS:
     def search(self, root_states: np.ndarray, root_n_carry: Optional[np.ndarray] = None) -> None:
         self.sync_weights()
         self.engine.search(root_states, root_n_carry)
+        if not self._cliff_warned and hasattr(self.engine, "search_info"):   # (the tests' CPU double of the engine has no kernel forms)
+            info = self.engine.search_info()
+            if info["kernel_form"] == "persistent" and info["tree_storage"] == "global" and info["lds_exit"] != "forced":
+                self._cliff_warned = True
+                warnings.warn(f"the trees of this search do not fit LDS residency ({info['lds_exit']}: {info['max_records']} records per tree, up to "
+                              f"{info['max_children']} children per node): they are kept in global memory -- same results, slower tree walk "
+                              "(BatchedMCTS.last_search_info)", RuntimeWarning, stacklevel=2)
+
+    @property
+    def last_search_info(self) -> dict:
+        """What the last search ran as (azg_search_info): ``kernel_form`` "persistent" / "per_layer" / "team", ``tree_storage`` "lds8" /
+        "lds9" / "global" with ``lds_exit`` saying which residency limit pushed the trees out of LDS, ``spec``, the workgroup shape,
+        ``team_fallbacks``, ``last_ms`` and the kernel's name."""
+        return self.engine.search_info()
 
     def results(self):
         return self.engine.results()

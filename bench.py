@@ -279,11 +279,7 @@ def time_search(eng, steps, warmup):
 
 def kernel_name(eng):
     """The kernel(s) the engine's last search ran as, in rocprofv3's spelling (the engine's own account, not a constant here)."""
-    import ctypes as C
-    from alphazero_gym_amd import _native
-    buf = C.create_string_buffer(256)
-    n = _native.lib().azg_debug_kernel_name(C.c_void_p(eng._h.value), buf, C.c_size_t(256))
-    return buf.value.decode() if n > 0 else "?"
+    return eng.search_info()["kernel_name"]
 
 
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E (MI355X_MICROARCH.md)
@@ -356,7 +352,7 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, f
     res = eng.results()
     assert (res["counts"].sum(1) == n_sims).all()
     ran = kernel_name(eng)
-    fallbacks = _native.lib().azg_debug_team_fallbacks(C.c_void_p(eng._h.value))
+    fallbacks = eng.search_info()["team_fallbacks"]
     walk = None
     if hbm or flops_per_sim is None:
         walk = tree_walk_bytes(eng.dump_tree(), kw.get("num_actions", 2), n_sims)
@@ -388,6 +384,60 @@ def extra_config(name, kw, trees, n_sims, in_dim, hidden, n_dist, act, expect, f
     return out
 
 
+def config_e_leg(args, rank, world, dev, dist, barrier):
+    """BASELINE.json configs[4] under N > 1: every rank searches its own shard of `--e-trees` trees (global tree ids rank * e_trees ..) with the
+    4x1024 network -- the reference's MCTSContinuous.search (alphazero/search/mcts.py:656-702) at E's sizes, no collective inside: K whole
+    searches bracketed by barriers, the max over ranks of the wall time, every rank's kernel form / fall-backs / event times gathered.
+    Returns the block rank 0 reports (None on the other ranks)."""
+    import ctypes as C
+    import torch
+    from alphazero_gym_amd import _capi, _native
+    from alphazero_gym_amd.synthetic import make_weights
+    T, K, hidden = args.e_trees, args.e_searches, [1024] * 4
+    e = _native.HipEngine(n_trees=T, n_sims=N_SIMS, tree_id_base=rank * T, device_id=dev, **PENDULUM)
+    e.set_weights(_capi.make_desc(3, hidden, 2, "elu"), make_weights(34, 3, hidden, 2))
+    e.upload_roots(e.synthetic_roots())
+    e.search_resident(); e.results_resident(); e.sync()     # warm-up (first launch of the kernel form, L2-cold weights)
+    barrier()
+    t0 = time.perf_counter()
+    ev = []
+    for _ in range(K):
+        e.search_resident()
+        e.results_resident()
+        e.sync()                                              # (a search is 12.7 ms: the event read between searches is noise)
+        ev.append(e.last_search_ms())
+    barrier()
+    wall = time.perf_counter() - t0
+    res = e.results()
+    assert (res["counts"].sum(1) == N_SIMS).all(), "config E leg: a tree does not hold n_sims visits"
+    name = kernel_name(e)
+    fallbacks = int(e.search_info()["team_fallbacks"])
+    e.close()
+    cpu = args.backend != "nccl"
+    mine = torch.tensor([wall, float(np.median(ev)), float(min(ev)), float(max(ev)), float(fallbacks)], dtype=torch.float64, device="cpu" if cpu else "cuda")
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    names = [None] * world
+    dist.all_gather_object(names, name)
+    if rank != 0:
+        return None
+    a = torch.stack(allr).cpu().numpy()
+    wall_max = float(a[:, 0].max())
+    ms = a[:, 1]
+    flop = mlp_flops(3, hidden, 3)
+    ach = T * N_SIMS * flop / (float(np.median(ms)) * 1e-3) / 1e12
+    return {"config": f"E: Pendulum-v1, 4x1024 ELU policy/value MLP, {world * T} trees = {T} per GPU x {N_SIMS} sims, {world} ranks (trees sharded by global id, "
+                      "no collective inside a search)",
+            "sims_per_s": world * T * N_SIMS * K / wall_max, "searches": K, "wall_ms_per_search_max_over_ranks": wall_max / K * 1e3,
+            "kernel_ms_per_search": {"min": float(ms.min()), "median": float(np.median(ms)), "max": float(ms.max()),
+                                     "note": "every rank's median over its searches (HIP events on the engine stream), then min / median / max over the ranks"},
+            "kernels": sorted(set(names)), "team_kernel_fallbacks_per_rank": [int(x) for x in a[:, 4]],
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
+                         "note": "per GPU, from the median rank's kernel time; 6 303 744 FLOP per simulation"},
+            "note": "sims of all ranks / max-over-ranks wall time of K searches + return_results; ranks that share one GPU (--same-device) "
+                    "time-slice it and their team kernels may fall back to the per-layer launches: reported, not an error"}
+
+
 def spawn(args):
     """`--gpus N` without torch.distributed.run around us: start it as a child process (this process has not touched the GPU
     or torch) and exit with its code; the child's rank 0 prints the JSON line."""
@@ -395,7 +445,7 @@ def spawn(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--trees", str(args.trees), "--bcast-every", str(args.bcast_every), "--gather-every", str(args.gather_every),
-           "--backend", args.backend, "--dist-timeout", str(args.dist_timeout)]
+           "--backend", args.backend, "--dist-timeout", str(args.dist_timeout), "--e-trees", str(args.e_trees), "--e-searches", str(args.e_searches)]
     for flag, on in (("--same-device", args.same_device), ("--config-d", args.config_d), ("--verify-gather", args.verify_gather),
                      ("--no-cpu-baseline", args.no_cpu_baseline)):
         if on:
@@ -423,6 +473,8 @@ def main():
     ap.add_argument("--dist-timeout", type=float, default=300.0, help="N > 1: seconds before a rendezvous / collective that does not complete "
                                                                       "(a dead rank) fails the run")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the config B / E lines")
+    ap.add_argument("--e-trees", type=int, default=1024, help="N > 1: trees per GPU of the config E leg (4x1024 MLP, BASELINE.json configs[4]: 8192 trees over 8 GPUs)")
+    ap.add_argument("--e-searches", type=int, default=5, help="N > 1: timed searches of the config E leg (0: skip the leg)")
     args = ap.parse_args()
 
     if args.traffic_probe:
@@ -594,6 +646,8 @@ def main():
             counts = gathered[:, 3 + eng.kmax:3 + 2 * eng.kmax].sum(1)
             assert bool((counts == N_SIMS).all()), "a gathered replay row does not hold n_sims visits"
         kmed, kmean = time_search(eng, 5, 0)
+        if dist is not None and args.e_searches > 0:
+            extra["config_e_nrank"] = config_e_leg(args, rank, world, dev, dist, barrier)
         workload = (f"config D: Pendulum-v1 A0C self-play, {world * B} games = {B} per GPU x {N_SIMS} sims per move, 2x256 ELU MLP; per step: "
                     f"search + final action + env step + replay row on the device; every {K} steps an all-gather of those steps' "
                     f"{world * K * B} replay rows ({world * K * B * RL * 4 / 1e6:.1f} MB, HBM to HBM, beside the next step's search); a weight "
@@ -660,7 +714,7 @@ def main():
                              mlp_flops(3, [1024] * 4, 3), "the team kernel with teams of 64 trees (64 x 64 tiles: a third fewer staged bytes per MFMA than the "
                              "32-tree teams' 32 x 64), two workgroups per CU, short staging chunks", dev),
                 extra_config("E's network at 3072 trees per GPU", PENDULUM, 3072, 200, 3, [1024] * 4, 2, "elu",
-                             "ls_team_kernel<2, 1024, false, 1, 2, 3, 0, 64>",
+                             "ls_team_kernel<2, 1024, false, 1, 2, 3, 1, 64>",
                              mlp_flops(3, [1024] * 4, 3), "64-tree teams, three workgroups per CU: while one waits at a hand-off or walks its trees the "
                              "other two keep the matrix pipe busy", dev),
             ]

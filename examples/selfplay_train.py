@@ -84,7 +84,9 @@ def train(a, log=print):
     for it in range(a.iters):
         rows = sp.collect_device(a.steps_per_iter, replay) if on_gpu else sp.collect(a.steps_per_iter)
         if world > 1:
-            rows = D.gather_replay_rows(rows, total=a.games)   # every rank's games (block lengths from shard_range: no length exchange)
+            # every rank plays a.games games for steps_per_iter steps: equal blocks, known without a length exchange (whatever a.games
+            # and the world size are: the job as a whole plays a.games * world games)
+            rows = D.gather_replay_rows(rows, counts=[rows.shape[0]] * world)
         info = {"loss": 0.0}
         pick = rng.choice(rows.shape[0], size=min(a.train_rows, rows.shape[0]), replace=False)
         if rank == 0:

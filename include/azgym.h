@@ -161,6 +161,39 @@ int azg_synthetic_roots(azg_engine* e, double* root_env_state /*[B][S_env]*/);
 /* timing of the last azg_search measured with HIP events on the engine stream (kernel only), milliseconds */
 int azg_last_search_ms(azg_engine* e, float* ms);
 
+/* What the last search ran as.  The engine picks a kernel form and a tree residency per search from the engine's parameters, and
+ * two of those choices are performance cliffs a caller should be able to see (nothing about the RESULTS changes):
+ *   - trees that do not fit LDS residency (more than 511 records = n_sims + 2, more than 16 children per node -- a large c_pw --,
+ *     or a network / batch whose LDS plan exceeds the CU's 160 KB) are kept in global memory: every tree-walk access becomes an
+ *     L2 / HBM round trip instead of an LDS one (lds_exit says which limit);
+ *   - a wide-network search whose persistent team kernel could not keep all its workgroups resident (a GPU shared with other work)
+ *     is redone by the per-layer launches (team_fallbacks counts them).
+ * The first search of an engine that leaves LDS residency prints one line to stderr (AZG_QUIET=1 silences it).
+ * Replaces the reference's nothing: its Python tree has one form (alphazero/search/mcts.py:418-462, 656-702). */
+enum { AZG_FORM_NONE = -1, AZG_FORM_PERSISTENT = 0 /* one launch = a whole search (search_kernel) */,
+       AZG_FORM_PER_LAYER = 1 /* wide networks: one launch per layer and tree phase of every simulation step */,
+       AZG_FORM_TEAM = 2 /* wide networks: one persistent launch, the batch cut into teams of workgroups (ls_team_kernel) */ };
+enum { AZG_TREES_GLOBAL = 0, AZG_TREES_LDS8 = 1 /* <= 255 records, 8-bit ids */, AZG_TREES_LDS9 = 2 /* <= 511 records */ };
+enum { AZG_LDS_RESIDENT = 0, AZG_LDS_EXIT_RECORDS = 1, AZG_LDS_EXIT_CHILDREN = 2, AZG_LDS_EXIT_SIZE = 3, AZG_LDS_EXIT_FORCED = 4 /* AZG_FORCE_GLOBAL_TREE=1 (tests) */,
+       AZG_LDS_NOT_APPLICABLE = 5 /* wide-network forms: the trees live in HBM by design (the team kernel stages its workgroup's two or four trees in LDS) */ };
+typedef struct azg_search_report {
+    int32_t struct_size;      /* sizeof(azg_search_report), set by the caller, checked */
+    int32_t kernel_form;      /* AZG_FORM_* */
+    int32_t tree_storage;     /* AZG_TREES_*: where the trees' hot records lived during the search */
+    int32_t lds_exit;         /* AZG_LDS_*: why they were not LDS-resident */
+    int32_t spec;             /* 1: the kernel compiled for epsilon 0 / lowest-index ties / the env's own action count (same results as 0) */
+    int32_t waves, groups, tile_trees;            /* persistent form: waves per workgroup, 16-tree groups per workgroup, trees per group */
+    int32_t team_trees, team_per_cu, team_parts;  /* team form: trees per team, workgroups per CU, launches the batch was cut into */
+    int32_t team_fallbacks;   /* searches of this engine that the team kernel gave up on and the per-layer launches redid (cumulative) */
+    int32_t max_records, max_children;            /* per tree: n_sims + 2 records; children per node the search can create */
+    float last_ms;            /* azg_last_search_ms */
+    char kernel_name[192];    /* the kernel of the last search as rocprofv3 names it */
+} azg_search_report;
+int azg_search_info(azg_engine* e, azg_search_report* info);
+
+/* diagnostic builds only (-DAZG_STAMPS, tools/phase_profile.py): per-wave cycle sums of the in-kernel phase stamps, [rows][16] */
+int azg_debug_stamps(azg_engine* e, unsigned long long* out, size_t max_rows);
+
 /* device-resident variant used by bench.py: roots already uploaded by a previous azg_search/azg_upload_roots;
  * runs the search kernel only (no host<->device copies) */
 int azg_upload_roots(azg_engine* e, const double* root_env_state, const int32_t* root_n_carry);

@@ -713,6 +713,9 @@ int azo_upload_roots(azg_engine* e, const double* roots, const int32_t* carry) {
         if (env_root_terminal(e->cfg.env_id, roots + (size_t)i * e->S_env))
             return fail(e, AZG_E_TERMINAL_ROOT, "Can't do tree search from a terminal node");
         if (carry && (carry[i] < 0 || carry[i] > (1 << 30))) return fail(e, AZG_E_INVALID, "root_n_carry out of range");
+        /* MCTSContinuous never reuses a tree (no forward(): mcts.py:589-600 builds a fresh root for every search) */
+        if (carry && carry[i] != 0 && e->cfg.mode == AZG_MODE_CONTINUOUS)
+            return fail(e, AZG_E_INVALID, "root_n_carry: continuous searches start from a fresh root (no carried count)");
     }
     memcpy(e->roots, roots, sizeof(double) * (size_t)e->cfg.n_trees * e->S_env);
     if (carry) memcpy(e->carry, carry, 4 * (size_t)e->cfg.n_trees); else memset(e->carry, 0, 4 * (size_t)e->cfg.n_trees);

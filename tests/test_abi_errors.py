@@ -77,4 +77,60 @@ def test_set_weights_validates_the_descriptor(engine_cls):
     assert (e.results()["counts"].sum(1) == 4).all()
     with pytest.raises(_capi.EngineError):
         e.search(np.zeros((2, 2)), carry=np.array([-1, 0]))                          # negative carried count
+    with pytest.raises(_capi.EngineError) as ei:
+        e.search(np.zeros((2, 2)), carry=np.array([0, 3]))                           # a carried count in continuous mode (mcts.py:589-600: fresh root)
+    assert ei.value.code == _capi.AZG_E_INVALID and "fresh root" in str(ei.value)
+    e.search(np.zeros((2, 2)), carry=np.array([0, 0]))
     e.close()
+
+
+@pytest.mark.gpu
+def test_search_info_reports_form_and_residency_through_the_abi(capfd):
+    """azg_search_info (include/azgym.h), called the way a C caller would: plain struct, struct_size checked.  It names the kernel form and
+    where the trees lived; a search whose trees do not fit LDS residency (600 simulations: 602 records > 511) still gives the right
+    visit totals, reports AZG_TREES_GLOBAL with AZG_LDS_EXIT_RECORDS and prints ONE line to stderr for the engine, not one per search."""
+    from alphazero_gym_amd import _native
+    lib = _native.lib()
+    info = _native.AzgSearchInfo()
+    e = _native.HipEngine(env_id=2, mode=1, n_trees=64, n_sims=40, c_uct=0.05, gamma=1.0)
+    h = C.c_void_p(e._h.value)
+    info.struct_size = 4
+    assert lib.azg_search_info(h, C.byref(info)) == _capi.AZG_E_INVALID            # wrong struct size: refused, nothing written
+    info.struct_size = C.sizeof(_native.AzgSearchInfo)
+    assert lib.azg_search_info(h, C.byref(info)) == 0 and info.kernel_form == -1   # AZG_FORM_NONE before the first search
+    e.set_weights(_capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2))
+    e.search(e.synthetic_roots())
+    assert lib.azg_search_info(h, C.byref(info)) == 0
+    assert info.kernel_form == 0 and info.tree_storage == 1 and info.lds_exit == 0 and info.spec == 1      # persistent, LDS8, resident, SPEC
+    assert (info.waves, info.groups, info.tile_trees) == (8, 1, 16) and info.max_records == 42
+    assert info.kernel_name.decode() == "search_kernel<2, 256, 1, 1, false, 8, 1, 16, 1>" and info.last_ms > 0
+    assert e.search_info()["tree_storage"] == "lds8"
+    e.close()
+    assert "LDS residency" not in capfd.readouterr().err
+    # beyond 511 records: global-memory trees, one warning for the engine
+    e = _native.HipEngine(env_id=2, mode=1, n_trees=32, n_sims=600, c_uct=0.05, gamma=1.0, kappa=0.3)   # (601^0.3: 7 children at most)
+    e.set_weights(_capi.make_desc(3, [64], 2, "elu"), O.make_weights(34, 3, [64], 2))
+    for _ in range(2):
+        e.search(e.synthetic_roots())
+    assert (e.results()["counts"].sum(1) == 600).all()
+    d = e.search_info()
+    assert d["kernel_form"] == "persistent" and d["tree_storage"] == "global" and d["lds_exit"] == "records" and d["max_records"] == 602
+    e.close()
+    assert capfd.readouterr().err.count("do not fit LDS residency (more than 511 records") == 1
+    # ... and the other residency limit: 600 simulations with the default widening law give the root 25 children (> 16)
+    e = _native.HipEngine(env_id=2, mode=1, n_trees=32, n_sims=600, c_uct=0.05, gamma=1.0)
+    e.set_weights(_capi.make_desc(3, [64], 2, "elu"), O.make_weights(34, 3, [64], 2))
+    e.search(e.synthetic_roots())
+    assert e.search_info()["lds_exit"] == "children" and e.search_info()["max_children"] == 25
+    e.close()
+    assert "more than 16 children per node" in capfd.readouterr().err
+    # wide networks: the team kernel (or, on a shared GPU, the per-layer launches), trees in HBM by design -- no warning
+    e = _native.HipEngine(env_id=2, mode=1, n_trees=64, n_sims=6, c_uct=0.05, gamma=1.0)
+    e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), O.make_weights(34, 3, [1024] * 4, 2))
+    e.search(e.synthetic_roots())
+    d = e.search_info()
+    assert d["kernel_form"] in ("team", "per_layer") and d["lds_exit"] == "not_applicable" and d["team_fallbacks"] in (0, 1)
+    if d["kernel_form"] == "team":
+        assert d["team_trees"] == 32 and d["team_parts"] == 1 and d["kernel_name"].startswith("ls_team_kernel<2, 1024")
+    e.close()
+    assert "LDS residency" not in capfd.readouterr().err

@@ -80,12 +80,13 @@ def test_multi_rank_loop_on_one_gpu(ranks):
     """`python bench.py --gpus N` spawns its own ranks; config D's step (self-play step, all-gather of the step's rows, weight
     broadcast + engine re-sync) runs with gloo and every rank on GPU 0: N = 2, 4 and 8 -- eight tree_id_base offsets, eight engines
     on one device, an eight-way gather, 256 games per rank (the shape of the driver's 8-GPU run has run once
-    before the driver tries it).  The N > 1 line carries the CPU baseline, a note about the traffic figure and
+    before the driver tries it), followed by the config E leg (4x1024 network, every rank its own shard of trees).  The N > 1 line carries the CPU baseline, a note about the traffic figure and
     every rank's host-side timings of the collectives (min / median / max over the ranks) with the world size each rank saw."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     trees = "256" if ranks == 8 else "512"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "5", "--warmup", "2", "--trees", trees,
-                        "--bcast-every", "2", "--backend", "gloo", "--same-device"], env=env, capture_output=True, text=True, timeout=900)
+                        "--bcast-every", "2", "--backend", "gloo", "--same-device", "--e-trees", "64", "--e-searches", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
@@ -100,6 +101,15 @@ def test_multi_rank_loop_on_one_gpu(ranks):
     assert pr["gathers_timed"] >= 1 and pr["bcasts_timed"] >= 1
     for k in ("gather_ms", "bcast_ms", "step_ms"):
         assert 0 < pr[k]["min"] <= pr[k]["median"] <= pr[k]["max"], (k, pr[k])
+    # BASELINE.json configs[4] under N > 1: every rank searched its own shard of the 4x1024 network's trees
+    # (64 here; ranks that share one GPU may see their team kernels fall back to the per-layer launches: reported, not an error)
+    e = out["extra"]["config_e_nrank"]
+    assert f"{ranks * 64} trees = 64 per GPU" in e["config"] and e["searches"] == 2
+    assert e["sims_per_s"] > 0 and len(e["team_kernel_fallbacks_per_rank"]) == ranks
+    km = e["kernel_ms_per_search"]
+    assert 0 < km["min"] <= km["median"] <= km["max"]
+    assert all(k.startswith(("ls_team_kernel", "lock-step", "ls_")) for k in e["kernels"]), e["kernels"]
+    assert 0 < e["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu

@@ -137,6 +137,56 @@ def _train_worker(rank, world, port, q, hip=False):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, q):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    out = {}
+    # (a) the training example's shape: every rank plays `games` games for `steps` steps, games % world != 0
+    games, steps = 3, 5
+    mine = torch.full((games * steps, 2), float(rank)) + torch.arange(games * steps, dtype=torch.float32)[:, None] / 100
+    out["equal"] = D.gather_replay_rows(mine, counts=[mine.shape[0]] * world).numpy()
+    # (b) a shard_range partition of fewer games than ranks: ranks 2.. hold nothing; rows per game stated, not inferred
+    total, rpg = 2, 3
+    lo, hi = D.shard_range(total, rank, world)
+    blk = torch.arange(lo * rpg, hi * rpg, dtype=torch.float32)[:, None].repeat(1, 2)
+    out["sparse"] = D.gather_replay_rows(blk, total=total, rows_per_game=rpg).numpy()
+    # (c) ... and inferring rows_per_game from an empty block is refused (on the ranks that cannot know it), before any collective
+    try:
+        D.gather_replay_rows(blk, total=total) if hi == lo else None
+        out["refused"] = hi != lo
+    except ValueError as ex:
+        out["refused"] = "rows_per_game" in str(ex)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_replay_rows_block_lengths_without_an_exchange():
+    """`total` is the games of the whole job; a rank without games contributes no rows when rows_per_game is given; equal
+    blocks of games x steps rows (the training example, games % world != 0) go through `counts`."""
+    world = 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        eq = got[r]["equal"]
+        assert eq.shape == (world * 15, 2)
+        for k in range(world):
+            np.testing.assert_array_equal(eq[15 * k:15 * (k + 1), 0], np.float32(k) + np.arange(15, dtype=np.float32) / 100)
+        np.testing.assert_array_equal(got[r]["sparse"][:, 0], np.arange(6, dtype=np.float32))
+        assert got[r]["refused"]
+
+
 @pytest.mark.parametrize("hip", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["oracle_double", "hip"])
 def test_two_rank_training_loop_keeps_weights_in_sync(hip):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

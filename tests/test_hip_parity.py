@@ -53,9 +53,7 @@ def test_mfma_f32_is_a_k_ordered_fma_chain(native):
 
 def _kernel_form(e):
     """What the HIP engine's last search ran as (engine_host.h: 0 search kernel, 1 per-layer launches, 2 team kernel)."""
-    import ctypes as C
-    from alphazero_gym_amd import _native
-    return _native.lib().azg_debug_kernel_form(C.c_void_p(e._h.value))
+    return e.search_info()["kernel_form_id"]
 
 
 _last_kernel_name = {}
@@ -69,11 +67,7 @@ def _run(engine_cls, kw, desc, blob, roots, carry=None, sidx=0, forms=None):
     out = (e.results(), e.dump_tree(), e.root_children(), e.root_eval())
     if forms is not None:
         forms.append(_kernel_form(e))
-        import ctypes as C
-        from alphazero_gym_amd import _native
-        buf = C.create_string_buffer(256)
-        _native.lib().azg_debug_kernel_name(C.c_void_p(e._h.value), buf, C.c_size_t(256))
-        _last_kernel_name["name"] = buf.value.decode()
+        _last_kernel_name["name"] = e.search_info()["kernel_name"]
     e.close()
     return out
 
@@ -206,7 +200,10 @@ def test_hip_bit_exact_vs_oracle(native, cfg, variant, monkeypatch):
     if variant == "no_spec":
         # register-resident one-layer networks with common parameters run kernels specialised at compile time (dispatch.cuh: SPEC);
         # this variant forces the general kernels on the same inputs
-        if len(hidden) != 2 or max(hidden) > 256 or ln or ncomp or extra.get("epsilon", 0.0) != 0.0 or n_sims > 126 or env in (3, 5):
+        # (SPEC kernels keep their trees in LDS with 8-bit ids: at most 255 records per tree -- n_sims + 2 in continuous mode, the root
+        # plus two edges per evaluated node in CartPole's discrete mode; cfg0, the headline shape with its 202 records, is one of them)
+        records = n_sims + 2 if mode == 1 else 1 + 2 * (n_sims + 1)
+        if len(hidden) != 2 or max(hidden) > 256 or ln or ncomp or extra.get("epsilon", 0.0) != 0.0 or records > 255 or env in (3, 5):
             pytest.skip("no compile-time specialised kernel exists for this configuration")
         monkeypatch.setenv("AZG_NO_SPEC", "1")
     if variant == "tile16":
@@ -330,12 +327,15 @@ def _assert_block_identical(r, d, ro, do, lo, hi):
         np.testing.assert_array_equal(do[k], d[k][lo:hi], err_msg=f"{k} trees {lo}..{hi}")
 
 
-@pytest.mark.parametrize("B", [4096, 8192 + 40])
-def test_full_size_properties(native, B):
+@pytest.mark.parametrize("B,no_spec", [(4096, False), (4096, True), (8192 + 40, False)], ids=["4096", "4096-no_spec", "8232"])
+def test_full_size_properties(native, B, no_spec, monkeypatch):
     """BASELINE config C (Pendulum-v1, 4096 trees, n_sims 200, 2x256 elu; mcts.py:656-702): size-independent invariants
      on every tree, and EVERY record of EVERY tree (results + whole tree dump) bit-exact against the oracle.
-    The larger, ragged batch takes the 8-wave / 32-tree workgroups."""
+    The larger, ragged batch takes the 8-wave / 32-tree workgroups.  no_spec: the general kernel (AZG_NO_SPEC=1) instead of the
+    compile-time specialised one the headline runs on -- the fallback path at the headline's size."""
     NS = 200
+    if no_spec:
+        monkeypatch.setenv("AZG_NO_SPEC", "1")
     kw = dict(env_id=2, mode=1, n_trees=B, n_sims=NS, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     desc = _capi.make_desc(3, [256, 256], 2, "elu")
     blob = O.make_weights(34, 3, [256, 256], 2)
@@ -344,6 +344,7 @@ def test_full_size_properties(native, B):
     roots = e.synthetic_roots()
     e.search(roots)
     r, d = e.results(), e.dump_tree()
+    assert e.search_info()["spec"] == (0 if no_spec else 1)
     e.close()
     assert (r["counts"].sum(1) == NS).all()                       # sum of root counts == n_sims
     assert (r["n_children"] == 15).all()                          # ceil(sqrt(200)) children at the root
@@ -459,7 +460,7 @@ def test_team_kernel_gives_up_instead_of_hanging(native, monkeypatch):
             e.search(e.synthetic_roots())
             e.search(e.synthetic_roots())
             out = dict(e.results(), **e.dump_tree())
-        n = native.lib().azg_debug_team_fallbacks(C.c_void_p(e._h.value))
+        n = e.search_info()["team_fallbacks"]
         e.close()
         return out, n
 
@@ -487,7 +488,7 @@ def test_team_kernel_in_two_launches_gives_up_as_one(native, monkeypatch):
         e.search(e.synthetic_roots())
         form = _kernel_form(e)
         out = dict(e.results(), **e.dump_tree())
-        n = native.lib().azg_debug_team_fallbacks(C.c_void_p(e._h.value))
+        n = e.search_info()["team_fallbacks"]
         e.close()
         return out, n, form
 

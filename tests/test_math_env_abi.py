@@ -183,7 +183,7 @@ def test_hip_library_exports_every_symbol_of_the_header():
     assert lib.azg_abi_version() == 1
     olib = O.lib()
     for n in names:
-        if n in ("azg_math_selftest",):
+        if n in ("azg_math_selftest", "azg_search_info", "azg_debug_stamps"):   # (about the device: kernel forms, LDS residency, stamps)
             continue
         assert hasattr(olib, "azo_" + n[4:]), n
 

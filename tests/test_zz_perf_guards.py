@@ -1,9 +1,7 @@
 """GPU (-m gpu): wall-clock guards of the three BASELINE searches, apart from the parity tests and collected LAST (the file
 name sorts behind every other test file): under the driver's `pytest -x` a slow, shared or throttled box can fail these without
-hiding a single correctness result.  Budgets are +25 % of the slowest time measured on this pool; the numbers the judge reads come
-from bench.py, not from here."""
-import ctypes as C
-
+hiding a single correctness result.  Budgets are the round-5 times measured on this pool + 15 % (the best of five searches is taken:
+box-to-box spread is 1-2 %); the numbers the judge reads come from bench.py, not from here."""
 import pytest
 
 import oracle_lib as O
@@ -33,35 +31,33 @@ def _best_ms(e, warm=3, timed=5):
 
 
 def _kernel_name(native, e):
-    buf = C.create_string_buffer(256)
-    native.lib().azg_debug_kernel_name(C.c_void_p(e._h.value), buf, C.c_size_t(256))
-    return buf.value.decode()
+    return e.search_info()["kernel_name"]
 
 
 def test_config_c_search_time(native):
-    """BASELINE config C (Pendulum-v1, 4096 trees x 200 sims, 2x256 ELU; mcts.py:656-702): 1.60-1.64 ms per search in round 4."""
+    """BASELINE config C (Pendulum-v1, 4096 trees x 200 sims, 2x256 ELU; mcts.py:656-702): 1.53-1.54 ms per search in round 5."""
     e = native.HipEngine(env_id=2, mode=1, n_trees=4096, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2))
     ms = _best_ms(e)
     name = _kernel_name(native, e)
     e.close()
     assert name.startswith("search_kernel<2, 256, 1, 1, false, 8, 1, 16"), name   # eight waves, four of them walking (DESIGN.md)
-    assert ms < 2.05, f"config C search took {ms:.3f} ms (budget 2.05 ms = 4.0e8 sims/s)"
+    assert ms < 1.77, f"config C search took {ms:.3f} ms (budget 1.77 ms = 4.6e8 sims/s)"
 
 
 def test_config_b_search_time(native):
-    """BASELINE config B (CartPole, 4096 trees x 100 sims, 2x128 ReLU; mcts.py:418-462): 0.34-0.37 ms per search in round 4."""
+    """BASELINE config B (CartPole, 4096 trees x 100 sims, 2x128 ReLU; mcts.py:418-462): 0.285-0.293 ms per search in round 5."""
     e = native.HipEngine(env_id=0, mode=0, n_trees=4096, n_sims=100, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
     e.set_weights(_capi.make_desc(4, [128, 128], 2, "relu"), O.make_weights(34, 4, [128, 128], 2))
     ms = _best_ms(e)
     e.close()
-    assert ms < 0.47, f"config B search took {ms:.3f} ms (budget 0.47 ms = 8.7e8 sims/s)"
+    assert ms < 0.33, f"config B search took {ms:.3f} ms (budget 0.33 ms = 1.24e9 sims/s)"
 
 
 def test_config_e_search_time(native):
-    """BASELINE config E per GPU (Pendulum-v1, 1024 trees x 200 sims, 4x1024 ELU): 13.1-13.3 ms per search in rounds 2-4."""
+    """BASELINE config E per GPU (Pendulum-v1, 1024 trees x 200 sims, 4x1024 ELU): 12.7-12.9 ms per search in round 5."""
     e = native.HipEngine(env_id=2, mode=1, n_trees=1024, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), O.make_weights(34, 3, [1024] * 4, 2))
     ms = _best_ms(e, warm=1, timed=3)
     e.close()
-    assert ms < 16.6, f"config E search took {ms:.1f} ms (budget 16.6 ms)"
+    assert ms < 14.6, f"config E search took {ms:.1f} ms (budget 14.6 ms)"

@@ -4,16 +4,32 @@ Read the SHARES, not the absolute time (stamps serialise the schedule).  GPU box
     make -C alphazero_gym_amd/csrc libazgym_hip_stamp.so && python tools/phase_profile.py [pendulum|cartpole] [trees]"""
 import ctypes as C
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASE_A = "--phase-a" in sys.argv   # slots 4..6 = phase A's parts (libazgym_hip_stampa.so) instead of the network's
-ENV_ONLY = "--env-only" in sys.argv  # libazgym_hip_stampe.so: ONE stamp pair (env step + observation of phase B): runs close to the product's time
-for flag in ("--phase-a", "--env-only"):
-    if flag in sys.argv:
-        sys.argv.remove(flag)
+# --only SLOT[a]: libazgym_hip_ss<SLOT>[a].so (make -C alphazero_gym_amd/csrc ss SLOT=..): ONE stamp pair, a build that runs close to
+# the product's time; prints that slot only ("a": slots 4..6 are phase A's parts).  --env-only = --only 15.
+ONLY = None
+if "--env-only" in sys.argv:
+    sys.argv.remove("--env-only")
+    ONLY = "15"
+if "--only" in sys.argv:
+    i = sys.argv.index("--only")
+    ONLY = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+if "--phase-a" in sys.argv:
+    sys.argv.remove("--phase-a")
+if ONLY and ONLY.endswith("a"):
+    PHASE_A = True
 os.environ["AZG_HIP_LIB"] = os.path.join(ROOT, "alphazero_gym_amd", "csrc",
-                                         "libazgym_hip_stampe.so" if ENV_ONLY else ("libazgym_hip_stampa.so" if PHASE_A else "libazgym_hip_stamp.so"))
+                                         f"libazgym_hip_ss{ONLY}.so" if ONLY else ("libazgym_hip_stampa.so" if PHASE_A else "libazgym_hip_stamp.so"))
+SLOT_NAMES = {0: "barrier wait in front of the network phase", 1: "network phase (whole)", 2: "tree phase A: finish leaf + backup", 3: "tree phase B: select / step / expand",
+              4: "mlp: layer 0 + ELU + publish", 5: "mlp: hidden MFMA loop (issue)", 6: "mlp: hidden activation", 7: "B per level: child records + division + U",
+              8: "B per level: scores + arg-max", 9: "B per level: chosen record", 10: "B per level: path slot + cold prefetch", 11: "B per level: full level",
+              12: "network phase, walking waves: the deferred half of phase B (tree_phase_b2)", 13: "B: whole descent", 14: "B: widening (noise, tanh, edge, child list)", 15: "B: env step + observation"}
+SLOT_NAMES_A = {4: "A: finish leaf (head sums, exp, cold store)", 5: "A: backup (return chain, records)", 6: "A: re-scoring + resume"}
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
@@ -39,10 +55,9 @@ def main():
     e.sync()
     print("kernel ms", e.last_search_ms())
     lib = _native.lib()
-    name = C.create_string_buffer(256)
-    lib.azg_debug_kernel_name(C.c_void_p(e._h.value), name, C.c_size_t(256))
-    print("kernel", name.value.decode())
-    args = name.value.decode().split("<")[1].rstrip(">").split(",")
+    kname = e.search_info()["kernel_name"]
+    print("kernel", kname)
+    args = kname.split("<")[1].rstrip(">").split(",")
     waves, groups, nt = int(args[5]), int(args[6]), int(args[7])   # search_kernel<ENV, HP, NREG, TLDS, GMM, NW, NG, NT>
     rows = (B + nt * groups - 1) // (nt * groups) * waves   # one row per wave
     buf = np.zeros((max(rows, (B + 3) // 4 * 4), 16), np.uint64)
@@ -56,6 +71,12 @@ def main():
         print(f"helper waves (4 of 8 per workgroup): barrier wait {buf[~walker, 0].astype(np.float64).mean() / (n_sims + 1):.0f}, network "
               f"{buf[~walker, 1].astype(np.float64).mean() / (n_sims + 1):.0f} cycles/step; the lines below are the WALKING waves")
         buf = buf[walker]
+    if ONLY:
+        k = int(re.match(r"\d+", ONLY).group(0))   # (suffixes: a = phase A's slots, c0 / c1 ... = A/B builds)
+        nm = (SLOT_NAMES_A if PHASE_A and k in SLOT_NAMES_A else SLOT_NAMES)[k]
+        v = buf[:, k].astype(np.float64) / (n_sims + 1)
+        print(f"single pair, slot {ONLY:>3s}: {nm:48s} mean {v.mean():8.0f} cycles/step  (min {v.min():8.0f}, max {v.max():8.0f} over the walking waves)")
+        return
     names = ["barrier wait", "network (MLP)", "finish leaf + backup", "select/step/expand"]
     tot = buf[:, :4].sum(1).mean()
     for i, nm in enumerate(names):

@@ -37,11 +37,10 @@ def main():
         for _ in range(9):
             e.search_resident()
             ms.append(e.last_search_ms())
-        buf = C.create_string_buffer(256)
-        _native.lib().azg_debug_kernel_name(C.c_void_p(e._h.value), buf, C.c_size_t(256))
+        kname = e.search_info()["kernel_name"]
         r = e.results()
         assert (r["counts"].sum(1) == ns).all()
-        print(f"{name:7s} {np.median(ms):8.4f} ms (min {min(ms):.4f})  {B * ns / np.median(ms) / 1e3:10.4e} sims/s  {buf.value.decode()}", flush=True)
+        print(f"{name:7s} {np.median(ms):8.4f} ms (min {min(ms):.4f})  {B * ns / np.median(ms) / 1e3:10.4e} sims/s  {kname}", flush=True)
         e.close()
 
 

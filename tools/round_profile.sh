@@ -19,7 +19,7 @@ fi
 TEAM_LIB=libazgym_hip_stampa.so python3 tools/team_profile.py 1024 > $OUT/${TAG}_team_profile.txt 2>&1
 TEAM_LIB=libazgym_hip_stampa.so python3 tools/team_profile.py 512 > $OUT/${TAG}_team_profile_alone.txt 2>&1
 # env step + observation of phase B with ONE stamp pair (a build that runs within a few per cent of the product): 8- and 4-wave kernels
-if [ -f alphazero_gym_amd/csrc/libazgym_hip_stampe.so ]; then
+if [ -f alphazero_gym_amd/csrc/libazgym_hip_ss15.so ]; then
   ( echo "== product library"; python3 tools/quick_times.py C B; AZG_WAVES=4 python3 tools/quick_times.py C
     echo "== one stamp pair (env step + observation), 8 waves"; python3 tools/phase_profile.py pendulum 4096 --env-only
     echo "== one stamp pair, 4 waves (AZG_WAVES=4)"; AZG_WAVES=4 python3 tools/phase_profile.py pendulum 4096 --env-only

@@ -29,13 +29,12 @@ assert lib.azg_debug_stamps(e._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), row
 flat = buf.reshape(-1).astype(np.float64) / (NS + 1)
 names = ["wait for observations", "tile layer 1 (+ layer 0)", "tile layer 2", "tile layer 3", "arrive + wait between layers",
          "wait for the last layer", "tree phases", "whole loop"]
-name = C.create_string_buffer(256)
-lib.azg_debug_kernel_name(C.c_void_p(e._h.value), name, C.c_size_t(256))
-TT = 64 if name.value.decode().rstrip(">").endswith(" 64") else 32
+kname = e.search_info()["kernel_name"]
+TT = 64 if kname.rstrip(">").endswith(" 64") else 32
 n_wg = (B + TT - 1) // TT * 16                              # teams of TT trees x 16 workgroups (HP = 1024)
 w = flat[:n_wg * 8].reshape(n_wg, 8)                        # [workgroup = team * 16 + slice][slot], cycles per step
 parts = flat[n_wg * 8:n_wg * 24].reshape(n_wg, 16)          # the tree phases' own parts
-print("kernel", name.value.decode(), "workgroups", n_wg)
+print("kernel", kname, "workgroups", n_wg)
 for i, nm in enumerate(names):
     v = w[:, i]
     print(f"  {nm:30s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles/step")

@@ -16,6 +16,6 @@ for B in (1024, 1536, 2048, 3072, 4096):
         e.search_resident(); e.sync()
         r = e.results()
         hs.add(hashlib.sha1(r["counts"].tobytes() + r["Q"].tobytes()).hexdigest())
-    fb = _native.lib().azg_debug_team_fallbacks(C.c_void_p(e._h.value))
+    fb = e.search_info()["team_fallbacks"]
     print(B, "distinct results:", len(hs), "fallbacks:", fb, "ms", e.last_search_ms())
     e.close()
