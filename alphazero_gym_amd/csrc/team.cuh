@@ -44,6 +44,9 @@
 #ifndef TEAM_SAME_XCD
 #define TEAM_SAME_XCD 1         // plain hand-off stores (kept in the XCD's L2) once the team is seen to sit on one XCD
 #endif
+#ifndef TEAM_DEFER
+#define TEAM_DEFER 1            // the new node's bookkeeping behind the workgroup's arrival at the hand-off (0: A/B builds)
+#endif
 #ifndef TEAM_LDS_COLD
 #define TEAM_LDS_COLD 1         // the default form (32-tree teams, two workgroups per CU, trees of <= 255 records): the cold records, returns and actions in LDS
 #endif                          // too (the weights-direct tile left the room), written out once at the end of the search
@@ -193,6 +196,12 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         action = (float*)(cb + (size_t)P.R * 72);
     }
     TreeState st = {};
+    // (the step's critical path through a workgroup ends with its trees' observations: what phase B does for the new node beyond that
+    // -- records, child list, reward, cold record -- waits until the workgroup has arrived at the hand-off)
+    // (MI355X, ms per search, same box: 1024 trees 12.71 -> 12.61, 1536 trees 17.56 -> 17.39; the 64-tree teams lose by it -- 2048 trees
+    // 22.33 -> 22.47, and the three-per-CU form has no five registers to spare -- and keep the bookkeeping inside phase B)
+    constexpr bool BDEF = TEAM_DEFER && ENV == AZG_ENV_PENDULUM_V1 && !GMM && TT == 32;
+    BDeferred bdef = {};
     // Is the whole team on one XCD?  Every workgroup reports its XCC_ID into two zero-initialised words of the team (max of id
     // and max of 7 - id: they add up to 7 only if all ids are equal) ahead of its first arrival; checked behind the first wait.
     // Until then, and whenever the answer is no, hand-off stores write through to memory (sc1).
@@ -304,8 +313,8 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         st.need_eval = false;
         TSTAMP(tp1);
         if (k < P.n_sims) {
-            __threadfence_block();
-            if (live) tree_phase_b<ENV, TLDS, GMM, TPW, int, true, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG);
+            tree_fence();
+            if (live) tree_phase_b<ENV, TLDS, GMM, TPW, int, true, false, SPEC, false, BDEF>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG, &bdef);
         }
         __builtin_amdgcn_s_setprio(0);   // (after the tree phases on every path, the last step's included)
         TSTAMP(tp2);
@@ -316,6 +325,12 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
             __syncthreads();
             first_layer(wt);
             team_arrive(cnt);
+            if constexpr (BDEF) {
+                // the rest of the node phase B has just created (tree_phases.cuh: DEFER): behind this workgroup's arrival, in the time the
+                // team's other workgroups need to get there
+                if (live) tree_phase_b2<ENV, TLDS, SPEC, true>(P, st, ts, cold, edge_W, action, bdef, sub);
+                bdef.pending = false;
+            }
         }
         TSTAMP(tf);
         TADD(6, te, tf);

@@ -93,7 +93,7 @@ static hipError_t team_launch_part(azg_engine* e, int g_base, int G, bool dry = 
 // dispatch_team_wide.hip, which is compiled with -mllvm -disable-machine-licm: with every loop-invariant constant and address hoisted out
 // of the simulation loop the three-per-CU forms spill (64-tree teams: 35 VGPRs, 140 B of scratch per lane; without the hoisting 6 / 24 B)
 // and run 1-3 % slower (1536 trees 18.05 -> 17.54 ms, 3072 trees 32.11 -> 31.82); the two-per-CU 32-tree form of config E itself is
-// 1.5 % FASTER with the hoisting (12.72 against 12.91 ms) and stays in dispatch_team.hip (MI355X, same box; profiles/r06_licm_ab.txt).
+// 1.5 % FASTER with the hoisting (12.72 against 12.91 ms) and stays in dispatch_team.hip (MI355X, same box; profiles/r06_ab_experiments.txt).
 #ifdef AZG_TEAM_WIDE_TU
 hipError_t azg_team_wide_forms(azg_engine* e, int g_base, int G, bool dry, bool common, bool t32, bool t64) {
     constexpr int ENV = AZG_ENV_PENDULUM_V1, HP = 1024, TLDS = TS_LDS8;

@@ -400,7 +400,7 @@ struct BDeferred {
 
 // the deferred half of phase B (Pendulum family: the nodes never end an episode).  The parent's records are read again here (nothing
 // has touched them since the descent): carrying them across the barrier would cost the lean walkers registers they do not have.
-template <int ENV, int TLDS, int SPEC>
+template <int ENV, int TLDS, int SPEC, bool FETCH = false>
 __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W, float* action,
                                               const BDeferred& d, int sub) {
     typedef typename TreeStore<TLDS>::Rec Rec;
@@ -427,6 +427,7 @@ __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, c
     // node's cold record (phase B stored the env state)
     const double sp[2] = {ps0, ps1};
     const double r = pendulum_reward(sp, d.cact) / P.reward_scale;
+    if constexpr (FETCH) { if (sub == (st.path_D & 15)) st.pr = r; }   // (the leaf's path slot: phase B left 0 there)
     if (sub == 0) {
         float zero = 0.0f;
         asm volatile("" : "+v"(zero));
@@ -440,12 +441,13 @@ __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, c
 // FETCH: the path's rewards / returns (st.pr, st.pW) are fetched on the way (false: the caller fetches them after the network phase).
 // RESUME (discrete mode, cached selections): the descent starts where the last trace's path is left (st.resume, set by
 // tree_phase_a<..., RESUME = true>) instead of at the root; the path slots above that depth are still in the lanes.
-// DEFER: the new node's records, reward and cold record are left to tree_phase_b2 (`def`); the caller fetches st.pr later (FETCH = false).
+// DEFER: the new node's records, reward and cold record are left to tree_phase_b2 (`def`), which also hands the leaf's path slot its
+// reward (st.pr) when the path's rewards travel in the lanes (FETCH).
 template <int ENV, int TLDS, bool GMM, int TPW = 16, typename PW = int, bool FETCH = true, bool RESUME = false, int SPEC = 0, bool OBS8 = false, bool DEFER = false>
 __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sub, int tl, unsigned gtree, const double* s_sqrt,
                                              const PW* s_pw, float* obsT STAMP_PARAM, BDeferred* def = nullptr) {
-    static_assert(!DEFER || (ENV == AZG_ENV_PENDULUM_V1 && !GMM && !FETCH), "deferred expansion: Pendulum family, squashed-Normal head, lean walkers");
+    static_assert(!DEFER || (ENV == AZG_ENV_PENDULUM_V1 && !GMM), "deferred expansion: Pendulum family, squashed-Normal head");
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
