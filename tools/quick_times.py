@@ -14,10 +14,12 @@ from alphazero_gym_amd.synthetic import make_weights  # noqa: E402
 
 PEND = dict(env_id=2, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
 CART = dict(env_id=0, mode=0, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
+MCC = dict(env_id=4, mode=1, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34, action_bound=1.0)   # MountainCarContinuous-v0
 SHAPES = {
     "C": (PEND, 4096, 200, 3, [256, 256], "elu"), "C8192": (PEND, 8192, 200, 3, [256, 256], "elu"), "C16384": (PEND, 16384, 200, 3, [256, 256], "elu"),
     "B": (CART, 4096, 100, 4, [128, 128], "relu"), "B2048": (CART, 2048, 100, 4, [128, 128], "relu"), "B1024": (CART, 1024, 100, 4, [128, 128], "relu"),
     "B16384": (CART, 16384, 100, 4, [128, 128], "relu"), "P128": (PEND, 4096, 200, 3, [128, 128], "elu"), "B8192": (CART, 8192, 100, 4, [128, 128], "relu"), "B256": (CART, 8192, 100, 4, [256, 256], "relu"),
+    "M": (MCC, 4096, 200, 2, [256, 256], "elu"), "M8192": (MCC, 8192, 200, 2, [256, 256], "elu"),
     "E": (PEND, 1024, 200, 3, [1024] * 4, "elu"), "E2048": (PEND, 2048, 200, 3, [1024] * 4, "elu"), "E3072": (PEND, 3072, 200, 3, [1024] * 4, "elu"),
 }
 

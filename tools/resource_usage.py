@@ -64,7 +64,7 @@ def main():
     tu = sys.argv[1] if len(sys.argv) > 1 else "dispatch_pendulum_large"
     flt = sys.argv[2] if len(sys.argv) > 2 else "kernel"
     extra = sys.argv[3:]
-    if tu in ("dispatch_pendulum_large", "dispatch_team_wide") and "-licm" not in " ".join(extra):   # (as alphazero_gym_amd/csrc/Makefile builds them)
+    if tu in ("dispatch_pendulum_large", "dispatch_team_wide", "dispatch_mcc") and "-licm" not in " ".join(extra):   # (as alphazero_gym_amd/csrc/Makefile builds them)
         extra = extra + ["-mllvm", "-disable-machine-licm"]
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, tu + ".s")
