@@ -142,7 +142,7 @@ struct LockStep {
 #else
 #define STAMP_ON(s1, s2) 1
 #endif
-#define STAMP3(var, s1, s2, s3) unsigned long long var = 0; if constexpr (STAMP_ON(s1, s2) || STAMP_ON(s3, s3)) { var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP3(var, s1, s2, s3) [[maybe_unused]] unsigned long long var = 0; if constexpr (STAMP_ON(s1, s2) || STAMP_ON(s3, s3)) { var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP2(var, s1, s2) STAMP3(var, s1, s2, -1)
 #define STAMP(var) STAMP2(var, -2, -2)
 #define STAMP_ADD(slot, t0, t1) do { if constexpr (STAMP_ON(slot, slot)) st_acc[slot] += (t1) - (t0); } while (0)
@@ -151,7 +151,7 @@ struct LockStep {
 #ifdef AZG_STAMPS_A   /* slots 4..6 = phase A's parts (finish leaf | backup | re-scoring) instead of the network's */
 #define STAMP_A(var, s1, s2) STAMP2(var, s1, s2)
 #define STAMP_A_ADD(slot, t0, t1) do { if constexpr (STAMP_ON(slot, slot)) { if (st_acc) st_acc[slot] += (t1) - (t0); } } while (0)
-#define STAMP_M(var, s1, s2) unsigned long long var = 0
+#define STAMP_M(var, s1, s2) [[maybe_unused]] unsigned long long var = 0
 #define STAMP_M_ADD(slot, t0, t1)
 #else
 #define STAMP_A(var, s1, s2)
