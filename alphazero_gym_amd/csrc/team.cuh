@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt STAMP_ARG);
         st.need_eval = false;
         TSTAMP(tp1);
+        if constexpr (BDEF) { if (k == 0 && live) eps_prepare(P, st, gtree, sub); }   // (no tree_phase_b2 in front of the first trace)
         if (k < P.n_sims) {
             tree_fence();
             if (live) tree_phase_b<ENV, TLDS, GMM, TPW, int, true, false, SPEC, false, BDEF>(P, st, ts, cold, edge_W, action, tb, sub, tj, gtree, s_sqrt, s_pw, s_obs STAMP_ARG, &bdef);
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
             if constexpr (BDEF) {
                 // the rest of the node phase B has just created (tree_phases.cuh: DEFER): behind this workgroup's arrival, in the time the
                 // team's other workgroups need to get there
-                if (live) tree_phase_b2<ENV, TLDS, SPEC, true>(P, st, ts, cold, edge_W, action, bdef, sub);
+                if (live) tree_phase_b2<ENV, TLDS, SPEC, true>(P, st, ts, cold, edge_W, action, bdef, sub, gtree);
                 bdef.pending = false;
             }
         }

@@ -20,6 +20,7 @@ struct TreeState {
     double pr, pW;        // ... and that record's reward and cumulative return W (consumed by backup_path)
     int kbase;            // progressive-widening noise cache: lane `sub` holds the N(0,1) draw of record kbase + sub
     float eps_c;          // per lane
+    float eps_next;       // (DEFER) the draw of record nrec, the next one to be created: taken out of the cache behind the barrier (eps_prepare)
     int ptop;             // LDS trees: next free 4-byte unit of the child-list pool
     int resume;           // discrete mode with cached selections: depth at which the next descent leaves the path of this trace (0: the root)
     double chainR;        // per lane: the slot's return of the last backup (reused when the next trace is the same trace again)
@@ -195,7 +196,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.nrec = 1; st.eps_draws = 0; st.leaf = 0; st.need_eval = live;
     st.path_D = 0; st.my_depth = -1; st.pid = 0; st.pr = 0.0; st.pW = 0.0;
-    st.kbase = 1; st.eps_c = 0.0f; st.ptop = 0; st.resume = 0; st.chainR = 0.0; st.repeat = false;
+    st.kbase = 1; st.eps_c = 0.0f; st.eps_next = 0.0f; st.ptop = 0; st.resume = 0; st.chainR = 0.0; st.repeat = false;
     if (CONT && live) st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
         double rs[S], sn;
 #pragma unroll
@@ -392,6 +393,17 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
 // barrier in front of the network phase); the new edge's and node's records, the parent's child list, the reward (a function of the
 // parent's state and the action only) and the cold record are written after that barrier, while the workgroup's non-walking waves
 // compute the first layer.
+// (DEFER) the progressive-widening noise of the NEXT record, made ready off the step's critical path: refill the 16-draw cache when the
+// next record lies beyond it (Philox + Box-Muller, once per 16 records) and fetch that record's draw from its lane.  Phase B then widens
+// with st.eps_next instead of a cross-lane read (and never refills).  Called behind the root's first action and at the end of tree_phase_b2.
+__device__ __forceinline__ void eps_prepare(const KParams& P, TreeState& st, unsigned gtree, int sub) {
+    if (st.nrec >= st.kbase + 16) {
+        st.kbase = st.nrec;
+        st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
+    }
+    st.eps_next = __shfl(st.eps_c, st.nrec - st.kbase, 16);
+}
+
 struct BDeferred {
     bool pending, widen;
     int p, chosen;          // parent node, the new record
@@ -402,7 +414,7 @@ struct BDeferred {
 // has touched them since the descent): carrying them across the barrier would cost the lean walkers registers they do not have.
 template <int ENV, int TLDS, int SPEC, bool FETCH = false>
 __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W, float* action,
-                                              const BDeferred& d, int sub) {
+                                              const BDeferred& d, int sub, unsigned gtree) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     static_assert(ENV == AZG_ENV_PENDULUM_V1, "deferred expansion: the Pendulum family");
     if (!d.pending) return;
@@ -434,6 +446,7 @@ __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, c
         Cold* c = cold + d.chosen;
         c->s[3] = 0.0; c->r = r; c->V = zero; c->mu = zero; c->sg = zero; c->pad = zero;
     }
+    eps_prepare(P, st, gtree, sub);
 }
 
 // Phase B: the next trace: descend by UCT / PUCT (selectionUCT: mcts.py:464-493, 704-741), widen or pick an unexpanded edge,
@@ -452,7 +465,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
     constexpr int S = CONT ? 2 : 4;
     typedef typename TreeStore<TLDS>::Rec Rec;
     st.need_eval = false;
-    if (CONT && st.nrec >= st.kbase + 16) {
+    if (CONT && !DEFER && st.nrec >= st.kbase + 16) {   // (DEFER: eps_prepare has done it)
         st.kbase = st.nrec;
         st.eps_c = azg_normal(P.seed, gtree, P.search_idx, (unsigned)(st.kbase + sub));
     }
@@ -555,7 +568,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             // MCTSContinuous.add_pw_action (mcts.py:625-654)
             const int K = hp.n_child;
             chosen = st.nrec++;
-            float eps = __shfl(st.eps_c, chosen - st.kbase, 16);
+            float eps = DEFER ? st.eps_next : __shfl(st.eps_c, chosen - st.kbase, 16);
             float wmu = cp.mu, wsg = cp.sg;
             if constexpr (GMM) {
                 float gd[15];
