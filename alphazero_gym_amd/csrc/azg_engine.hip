@@ -324,7 +324,7 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     P.tie_random = cfg->tie_break == AZG_TIE_RANDOM; P.env_id = cfg->env_id; P.v1 = cfg->env_id == AZG_ENV_PENDULUM_V1; P.tree_base = cfg->tree_id_base; P.mode = cfg->mode;
     P.c_uct = cfg->c_uct; P.gamma = cfg->gamma; P.epsilon = cfg->epsilon; P.reward_scale = cfg->reward_scale;
     P.c_uct_f = (float)cfg->c_uct; P.gamma_f = (float)cfg->gamma; P.bound_f = (float)cfg->action_bound;
-    P.seed = cfg->seed; P.S = e->S_env; P.tab_n = e->tab_n;
+    P.seed = cfg->seed; P.S = e->S_env; P.tab_n = e->tab_n; P.pw0 = cfg->mode == AZG_MODE_CONTINUOUS ? pw[0] : 0;
     P.roots = e->d_roots; P.carry = e->d_carry;
     P.hot = hot; P.cold = cold; P.edge_W = edge_W; P.action = action; P.prior = prior; P.child = child;
     P.n_rec = n_rec; P.pw_need = d_pw; P.sqrt_tab = d_sq;

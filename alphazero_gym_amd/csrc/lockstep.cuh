@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ls_tree_kernel(KParams P, LockStep L, int
         st.nrec = t.nrec; st.eps_draws = t.eps_draws; st.leaf = t.leaf; st.need_eval = live && t.need_eval; st.path_D = t.path_D;
         st.kbase = t.kbase; st.my_depth = ln.my_depth; st.pid = ln.pid; st.pr = ln.pr; st.pW = ln.pW; st.eps_c = ln.eps_c;
         if (live) tree_phase_a<ENV, false, GMM, NCH>(P, st, ts, cold, edge_W, action, tb, sim, sub, tl, gtree,
-                                                     L.parts + (size_t)tg * NCH * 64, P.bhead, s_sqrt);
+                                                     L.parts + (size_t)tg * NCH * 64, P.bhead, s_sqrt STAMP_ARG, s_pw);
         st.need_eval = false;
         if (sim < P.n_sims - 1) {
             __threadfence_block();

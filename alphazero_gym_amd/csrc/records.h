@@ -24,7 +24,8 @@ struct __attribute__((aligned(16))) RecS {
     unsigned short edge_n;   // edge visit count
     unsigned short node_n;   // node visit count
     unsigned char parent;    // record of the parent node
-    unsigned char n_child : 6;   // node: number of child edges (<= 16)
+    unsigned char n_child : 5;   // node: number of child edges (<= 16)
+    unsigned char wnext : 1;     // continuous mode: the node widens at its next visit (tree.cuh: set_wnext)
     unsigned char flags : 2;     // FLAG_EXPANDED | FLAG_TERMINAL
     unsigned char first;     // record of child edge 0 (discrete: the children are contiguous)
     unsigned char cbase;     // continuous, n_child >= 2: the child list starts at pool[4 * cbase];
@@ -42,6 +43,7 @@ struct __attribute__((aligned(16))) RecM {
     unsigned long long cbase : 9;
     unsigned long long n_child : 5;
     unsigned long long flags : 2;
+    unsigned long long wnext : 1;   // (as in RecS)
 };
 static_assert(sizeof(RecM) == 16, "RecM must be 16 bytes");
 // tree storage of a kernel variant: global memory (RecL), LDS with 8-bit ids (RecS), LDS with 9-bit ids (RecM)
@@ -56,7 +58,7 @@ struct __attribute__((aligned(8))) RecL {
     unsigned short n_child;
     unsigned short first;
     unsigned char flags;
-    unsigned char pad;       // discrete: index of the node's cached selection (rec_best)
+    unsigned char pad;       // discrete: index of the node's cached selection (rec_best); continuous: bit 0 = the node widens at its next visit
 };
 static_assert(sizeof(RecS) == 16, "RecS must be 16 bytes");
 static_assert(sizeof(RecL) == 24, "RecL must be 24 bytes");
@@ -115,6 +117,7 @@ struct KParams {
     int env_id;                 // AZG_ENV_* (the discrete family's kernels serve CartPole and MountainCar: env step chosen at run time)
     int trace_cap;              // discrete mode: traces a tree may run per simulation step (search_kernel.cuh; >= 1)
     int lds_state;              // discrete LDS trees: the env states of expanded nodes live in LDS too (set by the launch planning)
+    int pw0;                    // continuous mode: pw_need[0], the children a node without visits is entitled to (a new node widens at its first visit iff > 0)
     int publish;                // LDS trees: write them out in the global RecL format after the last trace (azg_dump_tree asks for it;
                                 // the product path's results come from the search kernel's epilogue and need no published tree)
     unsigned long long* stamps; // diagnostic build only (-DAZG_STAMPS): [grid][8] cycle sums per phase

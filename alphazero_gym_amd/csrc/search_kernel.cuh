@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
         if constexpr (DEFER) {
             // the rest of the node phase B has just created (the other waves are in the first layer meanwhile)
             STAMP2(t_b2a, 12, -1);
-            if (cx.live) tree_phase_b2<ENV, TLDS, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, bdef, cx.sub, cx.gtree);
+            if (cx.live) tree_phase_b2<ENV, TLDS, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, bdef, cx.sub, cx.gtree, s_pw);
             bdef.pending = false;
             STAMP2(t_b2b, 12, -1);
 #ifdef AZG_STAMP_ONLY
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
         }
         if constexpr (!MULTI) {
             // ================= tree phase A: finish the evaluated leaf, back up =================
-            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
+            if (cx.live) tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG, s_pw);
             if (sim == P.n_sims - 1) break;
             if constexpr (DEFER) { if (sim < 0 && cx.live) eps_prepare(P, st, cx.gtree, cx.sub); }   // (no tree_phase_b2 in front of the first trace)
             tree_fence();
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, NT < 16 ? 2 : 1) void search_kernel(KParam
             int k = 0;
             while (run) {
                 STAMP2(t_c2, 2, -1);
-                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG);
+                tree_phase_a<ENV, TLDS, GMM, NCH, PSTR, !CONT, SPEC>(P, st, cx.ts, cx.cold, cx.edge_W, cx.action, cx.tb, my_sim, cx.sub, cx.tl % NT, cx.gtree, cx.my_parts, s_bhead, s_sqrt STAMP_ARG, s_pw);
                 tree_fence();
                 STAMP2(t_d, 2, 3);
                 st.need_eval = false;

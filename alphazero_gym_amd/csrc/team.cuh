@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
         __syncthreads();
         TSTAMP(tp0);
         __builtin_amdgcn_s_setprio(3);   // the walking wave ahead of the other workgroups' MFMA waves on its SIMD (-0.7 % per search)
-        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt STAMP_ARG);
+        if (live) tree_phase_a<ENV, TLDS, GMM, NCH, 64, false, SPEC>(P, st, ts, cold, edge_W, action, tb, sim, sub, tj, gtree, s_ab, P.bhead, s_sqrt STAMP_ARG, s_pw);
         st.need_eval = false;
         TSTAMP(tp1);
         if constexpr (BDEF) { if (k == 0 && live) eps_prepare(P, st, gtree, sub); }   // (no tree_phase_b2 in front of the first trace)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, MINB) void ls_team_kernel(KParams P, LockStep 
             if constexpr (BDEF) {
                 // the rest of the node phase B has just created (tree_phases.cuh: DEFER): behind this workgroup's arrival, in the time the
                 // team's other workgroups need to get there
-                if (live) tree_phase_b2<ENV, TLDS, SPEC, true>(P, st, ts, cold, edge_W, action, bdef, sub, gtree);
+                if (live) tree_phase_b2<ENV, TLDS, SPEC, true>(P, st, ts, cold, edge_W, action, bdef, sub, gtree, s_pw);
                 bdef.pending = false;
             }
         }

@@ -127,7 +127,8 @@ template <typename RecT, typename IdT> struct TreeStoreLds {
     __device__ __forceinline__ int child_at(int, const Rec& hp, int i, int) const {
         return hp.n_child == 1 ? (int)hp.first : (int)pool[4 * (int)hp.cbase + i];
     }
-    __device__ __forceinline__ void child_append(int p, const Rec& hp, int K, int id, int& ptop, bool writer, int) const {
+    // (wnext: the parent's widens-at-next-visit bit with its K + 1 children, stored with the new child count)
+    __device__ __forceinline__ void child_append(int p, const Rec& hp, int K, int id, int& ptop, bool writer, int, bool wnext = false) const {
         const int cb = hp.cbase;
         if (K == 0) {
             if (writer) hot[p].first = (decltype(hp.first))id;
@@ -143,7 +144,7 @@ template <typename RecT, typename IdT> struct TreeStoreLds {
         } else {
             if (writer) pool[4 * cb + K] = (IdT)id;
         }
-        if (writer) hot[p].n_child = (decltype(hp.n_child))(K + 1);
+        if (writer) { hot[p].n_child = (decltype(hp.n_child))(K + 1); hot[p].wnext = wnext ? 1 : 0; }
     }
 };
 template <> struct TreeStore<TS_LDS8> : TreeStoreLds<RecS, unsigned char> {};
@@ -153,18 +154,33 @@ template <> struct TreeStore<TS_GLOBAL> {
     Rec* hot; unsigned short* child; float* prior;
     static constexpr double* state = nullptr;   // (global trees keep env states in their cold records)
     __device__ __forceinline__ int child_at(int p, const Rec&, int i, int Kp) const { return (int)child[p * Kp + i]; }
-    __device__ __forceinline__ void child_append(int p, const Rec&, int K, int id, int&, bool writer, int Kp) const {
+    __device__ __forceinline__ void child_append(int p, const Rec&, int K, int id, int&, bool writer, int Kp, bool wnext = false) const {
         if (writer) {
             child[p * Kp + K] = (unsigned short)id;
             hot[p].n_child = (unsigned short)(K + 1);
+            hot[p].pad = wnext ? 1 : 0;
         }
     }
 };
+
+// Continuous mode: "this node widens at its next visit" -- NodeContinuous.check_pw (states.py:271-275: ceil(c_pw (n + 1)^kappa) > number of
+// children) evaluated whenever the node's visit count or child count changes (backup, widening, creation) and kept with the node, so that
+// the descent reads it with the record instead of looking the threshold up behind it (one LDS round trip per level of the descent).
+__device__ __forceinline__ bool get_wnext(const RecS& h) { return h.wnext != 0; }
+__device__ __forceinline__ bool get_wnext(const RecM& h) { return h.wnext != 0; }
+__device__ __forceinline__ bool get_wnext(const RecL& h) { return (h.pad & 1) != 0; }
+__device__ __forceinline__ void set_wnext(RecS& h, bool w) { h.wnext = w ? 1 : 0; }
+__device__ __forceinline__ void set_wnext(RecM& h, bool w) { h.wnext = w ? 1 : 0; }
+__device__ __forceinline__ void set_wnext(RecL& h, bool w) { h.pad = w ? 1 : 0; }
+// the widening threshold of a node with n visits (the host-built table is clamped at n_sims + 1: records.h KParams::pw_need)
+template <typename PW>
+__device__ __forceinline__ int pw_at(const PW* s_pw, int n, int cap) { return (int)s_pw[n < cap ? n : cap]; }
 
 template <typename Rec>
 __device__ __forceinline__ Rec make_edge(double Q, int parent) {
     Rec h;
     h.Q = Q; h.edge_n = 0; h.node_n = 0; h.parent = (decltype(h.parent))parent; h.n_child = 0; h.flags = 0; h.first = 0;
+    set_wnext(h, false);
     return h;
 }
 __device__ __forceinline__ void clear_pad(RecS& h) { h.cbase = 0; }
@@ -176,9 +192,11 @@ __device__ __forceinline__ void clear_pad(RecL& h) { h.pad = 0; }
 // is part of the contract), then every lane updates its own record.
 // on_node(p): called (by all 16 lanes, p uniform) for every node whose statistics were updated here, after the update is stored
 // (the caller of backup_path looks after the nodes of the last 16 levels itself).
-template <bool CONT, int TLDS, typename F>
+// (continuous mode: s_pw / pw_cap = the widening thresholds, for the nodes' widens-at-next-visit bits: set_wnext)
+template <bool CONT, int TLDS, typename F, typename PW = int>
 __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, int j, float V, int sub,
-                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv, F&& on_node) {
+                                            float gamma_f, double gamma, bool firstlvl, bool at_leaf, double Rv, F&& on_node,
+                                            const PW* s_pw = nullptr, int pw_cap = 0) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     while (true) {
         int mine = 0, cnt = 0, jj = j;
@@ -219,7 +237,10 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
                 mrec.edge_n = (decltype(mrec.edge_n))en;
                 edge_W[mine] = Wn;
             }
-            if (!(at_leaf && sub == 0)) mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
+            if (!(at_leaf && sub == 0)) {
+                mrec.node_n = (decltype(mrec.node_n))(mrec.node_n + 1);
+                if constexpr (CONT) set_wnext(mrec, pw_at(s_pw, (int)mrec.node_n, pw_cap) - (int)mrec.n_child > 0);
+            }
             ts.hot[mine] = mrec;
         }
         if (!TLDS) tree_fence();
@@ -240,11 +261,11 @@ __device__ __forceinline__ void backup_from(const TreeStore<TLDS>& ts, const Col
 // tree_phase_b): every lane's return is the one it had, the serial chain is skipped.  r_uniform (discrete mode): the reward every
 // edge of the path carries (env.cuh: discrete_env_reward) except the last one, the edge into the leaf, which carries r_first (the
 // same value unless the leaf is terminal and the env pays differently on its last step: Acrobot).
-template <bool CONT, int TLDS, typename F>
+template <bool CONT, int TLDS, typename F, typename PW = int>
 __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Cold* cold, double* edge_W, float V, int sub, float gamma_f,
                                             double gamma, int D, int my_depth, int pid, double pr, double& pW, F&& on_node,
                                             typename TreeStore<TLDS>::Rec& rec, double& chainR, bool same_chain = false,
-                                            double r_uniform = 0.0, double r_first = 0.0) {
+                                            double r_uniform = 0.0, double r_first = 0.0, const PW* s_pw = nullptr, int pw_cap = 0) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     const int n0 = D < 16 ? D : 16;
     double Rv = 0.0, myR = 0.0;
@@ -303,6 +324,9 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
     clear_pad(rec);
     if (valid) {
         rec = ts.hot[pid];
+        // (continuous mode: the node's widening threshold at its new count, requested ahead of the division below)
+        int need = 0;
+        if constexpr (CONT) { if (my_depth < D) need = pw_at(s_pw, (int)rec.node_n + 1, pw_cap); }
         par = rec.parent;
         if (my_depth >= 1) {
             int en = (int)rec.edge_n + 1;
@@ -312,11 +336,14 @@ __device__ __forceinline__ void backup_path(const TreeStore<TLDS>& ts, const Col
             edge_W[pid] = Wn;
             pW = Wn;
         }
-        if (my_depth < D) rec.node_n = (decltype(rec.node_n))(rec.node_n + 1);
+        if (my_depth < D) {
+            rec.node_n = (decltype(rec.node_n))(rec.node_n + 1);
+            if constexpr (CONT) set_wnext(rec, need - (int)rec.n_child > 0);
+        }
         ts.hot[pid] = rec;
     }
     if (D >= 16) {
         int j = __shfl(par, (D - 15) & 15, 16);   // parent of the shallowest record handled above
-        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv, on_node);
+        backup_from<CONT, TLDS>(ts, cold, edge_W, j, V, sub, gamma_f, gamma, false, false, Rv, on_node, s_pw, pw_cap);
     }
 }

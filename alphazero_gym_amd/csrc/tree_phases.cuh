@@ -209,6 +209,7 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
             h.node_n = (decltype(h.node_n))P.carry[tree];
             h.flags = FLAG_EXPANDED;
             clear_pad(h);
+            if (CONT) set_wnext(h, pw_at(P.pw_need, (int)P.carry[tree], P.n_sims + 1) > 0);   // (no children yet)
             ts.hot[0] = h;
             Cold c;
 #pragma unroll
@@ -238,10 +239,11 @@ __device__ __forceinline__ void tree_init_root(const KParams& P, TreeState& st, 
 // action: mcts.py:673), then back the return up (mcts.py:241-267).  `parts` = the NCH partial head sums of the network phase
 // for the tree's group of 16 (PSTR entries per chunk), tl = the tree's column in that group.
 // RESUME (discrete mode, cached selections): also work out where the next descent leaves this trace's path (st.resume).
-template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false, int SPEC = 0>
+// s_pw: continuous mode, the widening thresholds (the backup keeps the path nodes' widens-at-next-visit bits: tree.cuh set_wnext).
+template <int ENV, int TLDS, bool GMM, int NCH, int PSTR = 64, bool RESUME = false, int SPEC = 0, typename PW = int>
 __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W,
                                              float* action, size_t tb, int sim, int sub, int tl, unsigned gtree, const f32x4* parts,
-                                             const float* bhead, const double* s_sqrt STAMP_PARAM_OPT) {
+                                             const float* bhead, const double* s_sqrt STAMP_PARAM_OPT, const PW* s_pw = nullptr) {
     constexpr bool CONT = EnvFamily<ENV>::CONT;
     typedef typename TreeStore<TLDS>::Rec Rec;
     float V = 0.0f;
@@ -283,7 +285,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                     edge_W[k] = 0.0;
                     action[k] = a;
                 }
-                ts.child_append(0, make_edge<Rec>(0.0, 0), 0, k, st.ptop, sub == 0, P.Kp);
+                ts.child_append(0, make_edge<Rec>(0.0, 0), 0, k, st.ptop, sub == 0, P.Kp,
+                                pw_at(P.pw_need, (int)ts.hot[0].node_n, P.n_sims + 1) - 1 > 0);   // (the root with its first child)
             }
         } else {
             // softmax priors + all num_actions edges with Q_init = V (MCTSDiscrete.evaluation, mcts.py:412-416)
@@ -355,7 +358,8 @@ __device__ __forceinline__ void tree_phase_a(const KParams& P, TreeState& st, co
                                 RESUME && !CONT && st.repeat,    // (only the kernels that resume descents set st.repeat)
                                 CONT ? 0.0 : discrete_env_reward(Spec<SPEC, ENV>::env(P)),
                                 // (a pending leaf that needs no evaluation is a terminal node: need_eval = !done)
-                                CONT ? 0.0 : (st.need_eval ? discrete_env_reward(Spec<SPEC, ENV>::env(P)) : discrete_env_terminal_reward(Spec<SPEC, ENV>::env(P))));
+                                CONT ? 0.0 : (st.need_eval ? discrete_env_reward(Spec<SPEC, ENV>::env(P)) : discrete_env_terminal_reward(Spec<SPEC, ENV>::env(P))),
+                                s_pw, P.n_sims + 1);
         STAMP_A(ta2, 5, 6);
         STAMP_A_ADD(5, ta1, ta2);   // backup (return chain, record updates)
         if constexpr (!CONT) {
@@ -412,9 +416,9 @@ struct BDeferred {
 
 // the deferred half of phase B (Pendulum family: the nodes never end an episode).  The parent's records are read again here (nothing
 // has touched them since the descent): carrying them across the barrier would cost the lean walkers registers they do not have.
-template <int ENV, int TLDS, int SPEC, bool FETCH = false>
+template <int ENV, int TLDS, int SPEC, bool FETCH = false, typename PW = int>
 __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, const TreeStore<TLDS>& ts, Cold* cold, double* edge_W, float* action,
-                                              const BDeferred& d, int sub, unsigned gtree) {
+                                              const BDeferred& d, int sub, unsigned gtree, const PW* s_pw) {
     typedef typename TreeStore<TLDS>::Rec Rec;
     static_assert(ENV == AZG_ENV_PENDULUM_V1, "deferred expansion: the Pendulum family");
     if (!d.pending) return;
@@ -427,13 +431,18 @@ __device__ __forceinline__ void tree_phase_b2(const KParams& P, TreeState& st, c
             Rec h = make_edge<Rec>((double)V, d.p);
             h.flags = FLAG_EXPANDED;
             clear_pad(h);
+            set_wnext(h, P.pw0 > 0);        // (a node without visits or children)
             ts.hot[d.chosen] = h;
             edge_W[d.chosen] = 0.0;
             action[d.chosen] = d.cact;
         }
-        ts.child_append(d.p, hp, (int)hp.n_child, d.chosen, st.ptop, sub == 0, P.Kp);
+        ts.child_append(d.p, hp, (int)hp.n_child, d.chosen, st.ptop, sub == 0, P.Kp,
+                        pw_at(s_pw, (int)hp.node_n, P.n_sims + 1) - ((int)hp.n_child + 1) > 0);
     } else if (sub == 0) {
-        ts.hot[d.chosen].flags = (unsigned char)FLAG_EXPANDED;
+        Rec h = ts.hot[d.chosen];
+        h.flags = FLAG_EXPANDED;
+        set_wnext(h, P.pw0 > 0);
+        ts.hot[d.chosen] = h;
     }
     // MCTS.expansion (mcts.py:216-238): the reward of the step that led here (mcts.py:687: divided by PENDULUM_R_SCALE) and the rest of the
     // node's cold record (phase B stored the env state)
@@ -504,8 +513,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
         STAMP3(tl0, 7, 8, 11);
         const int K = hp.n_child;
         if (CONT) {
-            int nn = (int)hp.node_n < P.n_sims + 1 ? (int)hp.node_n : P.n_sims + 1;
-            widen = (int)s_pw[nn] - K > 0;   // NodeContinuous.check_pw (states.py:271-275)
+            widen = get_wnext(hp);   // NodeContinuous.check_pw (states.py:271-275), evaluated when the node's counts last changed (tree.cuh: set_wnext)
             if (widen) break;
         }
         if (CONT || !Spec<SPEC, ENV>::plain(P)) {
@@ -586,7 +594,7 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
                     edge_W[chosen] = 0.0;
                     action[chosen] = cact;
                 }
-                ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp);
+                ts.child_append(p, hp, K, chosen, st.ptop, sub == 0, P.Kp, pw_at(s_pw, (int)hp.node_n, P.n_sims + 1) - (K + 1) > 0);
             }
         }
         // MCTS.expansion (mcts.py:216-238): step the env from the parent's cached state
@@ -633,7 +641,14 @@ __device__ __forceinline__ void tree_phase_b(const KParams& P, TreeState& st, co
             asm volatile("" : "+v"(zero));   // (made here: a zero vector kept in registers for the whole search costs four of them)
             c.r = r; c.V = zero; c.mu = zero; c.sg = zero; c.pad = zero;
             cold[chosen] = c;
-            ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+            if constexpr (CONT) {
+                Rec hn = ts.hot[chosen];
+                hn.flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+                set_wnext(hn, P.pw0 > 0);   // (a node without visits or children)
+                ts.hot[chosen] = hn;
+            } else {
+                ts.hot[chosen].flags = (unsigned char)(FLAG_EXPANDED | (done ? FLAG_TERMINAL : 0));
+            }
             if constexpr (!CONT && TLDS != TS_GLOBAL) {
                 if (ts.state && !done) {   // the next node to be evaluated in this tree: its edges will start at record nrec
                     double* sp = ts.state + 4 * (Spec<SPEC, ENV>::A(P) == 2 ? (st.nrec - 1) >> 1 : (st.nrec - 1) / P.A);
