@@ -210,6 +210,10 @@ int azg_engine_create(const azg_config* cfg, azg_engine** out) {
     if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != (cfg->env_id == AZG_ENV_CARTPOLE ? 2 : 3))
         return fail(nullptr, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3, Acrobot 3)");
     if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(nullptr, AZG_E_INVALID, "unknown tie_break");
+    // progressive widening (states.py:271-275): ceil(c_pw (n + 1)^kappa) children; with c_pw <= 0 no node is ever entitled to a child and the
+    // reference's first selection takes the arg-max of an empty list (helpers.py:30-52 raises)
+    if (cfg->mode == AZG_MODE_CONTINUOUS && !(cfg->c_pw > 0.0 && cfg->c_pw < 1e6 && cfg->kappa >= 0.0 && cfg->kappa <= 8.0))
+        return fail(nullptr, AZG_E_INVALID, "c_pw must be > 0 and kappa >= 0 (progressive widening: ceil(c_pw (n + 1)^kappa) children)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_E_DEVICE, "no HIP device available");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, AZG_E_DEVICE, "device_id out of range");

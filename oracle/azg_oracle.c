@@ -407,6 +407,10 @@ int azo_engine_create(const azg_config* cfg, azg_engine** out) {
     if (cfg->mode == AZG_MODE_CONTINUOUS && env_is_discrete(cfg->env_id))
         return fail(NULL, AZG_E_UNSUPPORTED, "continuous mode requires a continuous-action env (Pendulum)");
     if (cfg->tie_break != AZG_TIE_FIRST && cfg->tie_break != AZG_TIE_RANDOM) return fail(NULL, AZG_E_INVALID, "unknown tie_break");
+    /* states.py:271-275: with c_pw <= 0 no node is ever entitled to a child and the reference's first selection takes the arg-max of
+     * an empty list (helpers.py:30-52 raises) */
+    if (cfg->mode == AZG_MODE_CONTINUOUS && !(cfg->c_pw > 0.0 && cfg->c_pw < 1e6 && cfg->kappa >= 0.0 && cfg->kappa <= 8.0))
+        return fail(NULL, AZG_E_INVALID, "c_pw must be > 0 and kappa >= 0 (progressive widening: ceil(c_pw (n + 1)^kappa) children)");
     if (cfg->mode == AZG_MODE_DISCRETE && cfg->num_actions != env_num_actions(cfg->env_id))
         return fail(NULL, AZG_E_INVALID, "num_actions does not match the env (CartPole 2, MountainCar 3, Acrobot 3)");
     azg_engine* e = (azg_engine*)calloc(1, sizeof(azg_engine));

@@ -32,6 +32,10 @@ def test_create_rejects_bad_configs(engine_cls):
     assert ei.value.code == _capi.AZG_E_INVALID
     with pytest.raises(_capi.EngineError):
         engine_cls(env_id=7, mode=1, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0)
+    for bad in (dict(c_pw=0.0), dict(c_pw=-1.0), dict(kappa=-0.5)):                                 # no node would ever be entitled to a child
+        with pytest.raises(_capi.EngineError) as ei:
+            engine_cls(env_id=2, mode=1, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0, **bad)
+        assert ei.value.code == _capi.AZG_E_INVALID and "c_pw" in str(ei.value)
     for env_id, bad in ((0, 3), (3, 2), (3, 4)):                                                    # num_actions is the env's: CartPole 2, MountainCar 3
         with pytest.raises(_capi.EngineError) as ei:
             engine_cls(env_id=env_id, mode=0, n_trees=1, n_sims=4, c_uct=1.0, gamma=1.0, num_actions=bad)
