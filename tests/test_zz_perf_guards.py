@@ -1,6 +1,6 @@
 """GPU (-m gpu): wall-clock guards of the three BASELINE searches, apart from the parity tests and collected LAST (the file
 name sorts behind every other test file): under the driver's `pytest -x` a slow, shared or throttled box can fail these without
-hiding a single correctness result.  Budgets are the round-5 times measured on this pool + 15 % (the best of five searches is taken:
+hiding a single correctness result.  Budgets are the round-6 times measured on this pool + 15 % (the best of five searches is taken:
 box-to-box spread is 1-2 %); the numbers the judge reads come from bench.py, not from here."""
 import pytest
 
@@ -35,29 +35,29 @@ def _kernel_name(native, e):
 
 
 def test_config_c_search_time(native):
-    """BASELINE config C (Pendulum-v1, 4096 trees x 200 sims, 2x256 ELU; mcts.py:656-702): 1.53-1.54 ms per search in round 5."""
+    """BASELINE config C (Pendulum-v1, 4096 trees x 200 sims, 2x256 ELU; mcts.py:656-702): 1.50-1.53 ms per search in round 6."""
     e = native.HipEngine(env_id=2, mode=1, n_trees=4096, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [256, 256], 2, "elu"), O.make_weights(34, 3, [256, 256], 2))
     ms = _best_ms(e)
     name = _kernel_name(native, e)
     e.close()
     assert name.startswith("search_kernel<2, 256, 1, 1, false, 8, 1, 16"), name   # eight waves, four of them walking (DESIGN.md)
-    assert ms < 1.77, f"config C search took {ms:.3f} ms (budget 1.77 ms = 4.6e8 sims/s)"
+    assert ms < 1.73, f"config C search took {ms:.3f} ms (budget 1.73 ms = 4.7e8 sims/s)"
 
 
 def test_config_b_search_time(native):
-    """BASELINE config B (CartPole, 4096 trees x 100 sims, 2x128 ReLU; mcts.py:418-462): 0.285-0.293 ms per search in round 5."""
+    """BASELINE config B (CartPole, 4096 trees x 100 sims, 2x128 ReLU; mcts.py:418-462): 0.252-0.269 ms per search in round 6."""
     e = native.HipEngine(env_id=0, mode=0, n_trees=4096, n_sims=100, c_uct=1.5, gamma=1.0, num_actions=2, seed=34)
     e.set_weights(_capi.make_desc(4, [128, 128], 2, "relu"), O.make_weights(34, 4, [128, 128], 2))
     ms = _best_ms(e)
     e.close()
-    assert ms < 0.33, f"config B search took {ms:.3f} ms (budget 0.33 ms = 1.24e9 sims/s)"
+    assert ms < 0.30, f"config B search took {ms:.3f} ms (budget 0.30 ms = 1.37e9 sims/s)"
 
 
 def test_config_e_search_time(native):
-    """BASELINE config E per GPU (Pendulum-v1, 1024 trees x 200 sims, 4x1024 ELU): 12.7-12.9 ms per search in round 5."""
+    """BASELINE config E per GPU (Pendulum-v1, 1024 trees x 200 sims, 4x1024 ELU): 12.5-12.7 ms per search in round 6."""
     e = native.HipEngine(env_id=2, mode=1, n_trees=1024, n_sims=200, c_uct=0.05, gamma=1.0, c_pw=1.0, kappa=0.5, seed=34)
     e.set_weights(_capi.make_desc(3, [1024] * 4, 2, "elu"), O.make_weights(34, 3, [1024] * 4, 2))
     ms = _best_ms(e, warm=1, timed=3)
     e.close()
-    assert ms < 14.6, f"config E search took {ms:.1f} ms (budget 14.6 ms)"
+    assert ms < 14.4, f"config E search took {ms:.1f} ms (budget 14.4 ms)"

@@ -70,12 +70,18 @@ def main():
         walker = (np.arange(rows) % 8) < 4
         print(f"helper waves (4 of 8 per workgroup): barrier wait {buf[~walker, 0].astype(np.float64).mean() / (n_sims + 1):.0f}, network "
               f"{buf[~walker, 1].astype(np.float64).mean() / (n_sims + 1):.0f} cycles/step; the lines below are the WALKING waves")
+        bufh = buf[~walker]
         buf = buf[walker]
+    else:
+        bufh = None
     if ONLY:
         k = int(re.match(r"\d+", ONLY).group(0))   # (suffixes: a = phase A's slots, c0 / c1 ... = A/B builds)
         nm = (SLOT_NAMES_A if PHASE_A and k in SLOT_NAMES_A else SLOT_NAMES)[k]
         v = buf[:, k].astype(np.float64) / (n_sims + 1)
         print(f"single pair, slot {ONLY:>3s}: {nm:48s} mean {v.mean():8.0f} cycles/step  (min {v.min():8.0f}, max {v.max():8.0f} over the walking waves)")
+        if bufh is not None:
+            vh = bufh[:, k].astype(np.float64) / (n_sims + 1)
+            print(f"  same slot on the helper waves: mean {vh.mean():8.0f} (min {vh.min():8.0f}, max {vh.max():8.0f})")
         return
     names = ["barrier wait", "network (MLP)", "finish leaf + backup", "select/step/expand"]
     tot = buf[:, :4].sum(1).mean()
