@@ -41,8 +41,11 @@ __device__ __forceinline__ f32x4 expm1f4_nonpos(f32x4 xc) {
 // for bit (the sign of a zero that v_max / v_med3 may pick differently from the host's select vanishes in the sum)
 template <bool RARE = true>
 __device__ __forceinline__ f32x4 act4(int act, f32x4 v) {
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 pos = __builtin_elementwise_max(v, zero);
+    // max(x, 0) in one instruction per value (the max builtin first quiets a possible signalling NaN with a second v_max; so does
+    // fmed3(x, 0, inf), which the compiler turns into the same pair)
+    f32x4 pos;
+    asm("v_max_f32 %0, 0, %1" : "=v"(pos.x) : "v"(v.x)); asm("v_max_f32 %0, 0, %1" : "=v"(pos.y) : "v"(v.y));
+    asm("v_max_f32 %0, 0, %1" : "=v"(pos.z) : "v"(v.z)); asm("v_max_f32 %0, 0, %1" : "=v"(pos.w) : "v"(v.w));
     if (act == AZG_ACT_ELU) {
         f32x4 neg;
         neg.x = __builtin_amdgcn_fmed3f(v.x, -87.0f, 0.0f); neg.y = __builtin_amdgcn_fmed3f(v.y, -87.0f, 0.0f);
