@@ -89,11 +89,12 @@ def test_set_weights_validates_the_descriptor(engine_cls):
 
 
 @pytest.mark.gpu
-def test_search_info_reports_form_and_residency_through_the_abi(capfd):
+def test_search_info_reports_form_and_residency_through_the_abi(capfd, monkeypatch):
     """azg_search_info (include/azgym.h), called the way a C caller would: plain struct, struct_size checked.  It names the kernel form and
     where the trees lived; a search whose trees do not fit LDS residency (600 simulations: 602 records > 511) still gives the right
     visit totals, reports AZG_TREES_GLOBAL with AZG_LDS_EXIT_RECORDS and prints ONE line to stderr for the engine, not one per search."""
     from alphazero_gym_amd import _native
+    monkeypatch.delenv("AZG_QUIET", raising=False)   # (the warning this test counts is what AZG_QUIET=1 silences)
     lib = _native.lib()
     info = _native.AzgSearchInfo()
     e = _native.HipEngine(env_id=2, mode=1, n_trees=64, n_sims=40, c_uct=0.05, gamma=1.0)
