@@ -78,7 +78,7 @@ static hipError_t launch_t(azg_engine* e) {
 // The general shape is the 4-wave / 16-tree workgroup.  2x256 squashed-Normal networks (continuous mode) run with eight waves: while
 // every 16-tree group can have a CU of its own, as 16-tree workgroups whose eight waves share the network phase and whose first four
 // walk the trees (4 % faster than four waves; with all eight walking it only tied); once a batch has more groups than the device has
-// CUs, as 32-tree workgroups: one wave's tree walk and activation math overlaps the other's MFMAs (1.27x at 8192 trees).
+// CUs, as 32-tree workgroups: two groups per network phase, the second wave of a SIMD in the other's LDS / memory waits (1.27x at 8192 trees).
 // AZG_WAVES=4|8, AZG_GROUPS=1|2 force a shape (tests).
 template <int ENV, int HP, int NREG>
 static hipError_t launch(azg_engine* e) {

@@ -2,8 +2,9 @@
 // owns NG groups of 16 trees (one 16-column MFMA tile each):
 //   NW = 4, NG = 1: one wave per SIMD, 4 trees per wave (any network);
 //   NW = 8, NG = 1: two waves per SIMD for the network phase, four of the eight walk the trees (4 each): the shape of BASELINE config C;
-//   NW = 8, NG = 2: two waves per SIMD, 32 trees: one wave's tree walk / activation math overlaps the other's MFMAs
-//                   (pays off when the batch has more 16-tree groups than the device has CUs).
+//   NW = 8, NG = 2: two waves per SIMD, 32 trees = two groups that share every network phase (one barrier per step) and walk together, all
+//                   eight waves walking: the second wave of a SIMD fills the other's LDS / memory waits, nothing more -- MFMA and vector
+//                   time of a SIMD add up -- (pays off when the batch has more 16-tree groups than the device has CUs).
 // NT < 16 ("half-filled tiles"): a group holds only NT = 8 (or 4) trees, the other columns of its MFMA tile carry zeros: more,
 // smaller workgroups.  Measured on MI355X (config B's network, ms per search at 2048 / 4096 / 8192 trees): NT = 16: 0.469 / 0.482 /
 // 0.626; NT = 8: 0.451 / 0.594 / 1.115; NT = 4: 0.549 / 1.049 / 2.040.  A step of a workgroup takes about as long with 8 trees

@@ -698,7 +698,7 @@ def main():
             extra["configs"] = [
                 extra_config("C at 8192 trees per GPU (the batch shape of real self-play runs: two 16-tree groups per CU)", PENDULUM, 8192, 200, 3, HIDDEN, 2, "elu",
                              "search_kernel<2, 256, 1, 1, false, 8, 2, 16, 1>", FLOP_PER_SIM,
-                             "8-wave / 32-tree workgroups: two waves per SIMD, one's tree walk and activation math under the other's MFMAs", dev),
+                             "8-wave / 32-tree workgroups: two 16-tree groups share every network phase and walk together, two waves per SIMD (the second one fills the other's LDS / memory waits; MFMA and vector time add up)", dev),
                 extra_config("B: CartPole-v1 discrete, 4096 trees, n_sims=100, 2x128 ReLU", CARTPOLE, 4096, 100, 4, [128, 128], 2, "relu",
                              B_KERNEL, None,
                              "tree-walk bound (8-9 levels per trace, about 0.2 evaluations per simulation -- counted from the trees --: the MFMA "
